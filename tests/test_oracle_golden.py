@@ -1,0 +1,127 @@
+"""CPU: pin the oracle (oracle/) against the golden vectors generated from the reference's own
+modules (tests/golden/make_golden.py) and against the reference's own known-answer facts."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, GEN_CASES, PROG_CASES, DIS_CASES, load_case, oracle_fwd_bwd, oracle_forward, rel_err, grads_close
+from oracle import models as om, ops as oo, losses as ol
+
+TOL = 2e-5     # oracle vs reference on the same CPU/torch build: only summation order differs
+
+
+@pytest.mark.parametrize('name', GEN_CASES + PROG_CASES + DIS_CASES)
+def test_oracle_matches_reference_golden(name):
+    z, cfg, state, grads, after = load_case(name)
+    x, r = torch.from_numpy(z['x']), torch.from_numpy(z['r'])
+    out, gx, pg, new = oracle_fwd_bwd(cfg, state, x, r)
+    assert rel_err(out, z['out']) < TOL
+    assert rel_err(gx, z['grad_x']) < TOL
+    assert set(pg) == set(grads)
+    assert grads_close(pg, grads, 5e-4) == []
+    for k in after:
+        assert rel_err(new[k].float(), after[k].float()) < TOL, k
+    # second training forward on the advanced state, then eval forward
+    st2 = dict(state)
+    st2.update(new)
+    with torch.no_grad():
+        out2, new2 = oracle_forward(cfg, st2, x, True)
+        assert rel_err(out2, z['out2']) < TOL
+        st2.update(new2)
+        oute, _ = oracle_forward(cfg, st2, x, False)
+        assert rel_err(oute, z['out_eval']) < TOL
+
+
+def test_oracle_discriminator_srgan_lists():
+    """Full SRGAN feature/stride lists (model_discriminator.py:22-24 docstring) on 32x32."""
+    import json
+    from oracle import init as oi
+    z = np.load(os.path.join(GOLDEN, 'dis_32px_srgan.npz'))
+    cfg = json.loads(str(z['cfg']))
+    shapes = discriminator_shapes(cfg['input_shape'], cfg['list_n_features'])
+    state = oi.synth_state(shapes, cfg['state_seed'])
+    x, r = torch.from_numpy(z['x']), torch.from_numpy(z['r'])
+    out, gx, pg, _ = oracle_fwd_bwd(cfg, state, x, r)
+    assert rel_err(out, z['out']) < TOL and rel_err(gx, z['grad_x']) < 1e-4
+    ref, got = {}, {}
+    for k in z.files:
+        if k.startswith('grad/'):
+            ref[k[5:]], got[k[5:]] = torch.from_numpy(z[k]), pg[k[5:]]
+        if k.startswith('gradsample/'):
+            flat = pg[k[11:]].reshape(-1)
+            ref[k[11:]] = torch.from_numpy(z[k])
+            got[k[11:]] = flat[:: max(1, flat.numel() // 4096)][:4096]
+    assert grads_close(got, ref, 5e-4) == []
+
+
+def discriminator_shapes(input_shape, feats):
+    c, h, w = input_shape
+    n_s2 = len(feats) // 2
+    shapes = {'conv.0.bias': (feats[0],), 'conv.0.weight_orig': (feats[0], c, 3, 3),
+              'conv.0.weight_u': (feats[0],), 'conv.0.weight_v': (c * 9,)}
+    for i in range(1, len(feats)):
+        p = 'conv.2.%d.layers.' % (i - 1)
+        shapes.update({p + '0.bias': (feats[i],), p + '0.weight_orig': (feats[i], feats[i - 1], 3, 3),
+                       p + '0.weight_u': (feats[i],), p + '0.weight_v': (feats[i - 1] * 9,),
+                       p + '1.weight': (feats[i],), p + '1.bias': (feats[i],),
+                       p + '1.running_mean': (feats[i],), p + '1.running_var': (feats[i],),
+                       p + '1.num_batches_tracked': ()})
+    fc_in = h * w * feats[-1] // 4 ** n_s2
+    shapes.update({'fc.0.weight': (feats[-1] * 2, fc_in), 'fc.0.bias': (feats[-1] * 2,),
+                   'fc.2.weight': (1, feats[-1] * 2), 'fc.2.bias': (1,)})
+    return shapes
+
+
+def test_bicubic_golden_and_reference_facts(golden_dir):
+    z = np.load(golden_dir + '/bicubic.npz')
+    for i in range(int(z['n'])):
+        x = torch.from_numpy(z['x%d' % i]).requires_grad_(True)
+        size = tuple(int(v) for v in z['size%d' % i])
+        y = oo.bicubic_align_corners(x, size)
+        assert float((y - torch.from_numpy(z['interp%d' % i])).abs().max()) < 2e-6
+        assert float((oo.lr_from_hr(x, size) - torch.from_numpy(z['lr%d' % i])).abs().max()) < 2e-6
+        (y * torch.from_numpy(z['r%d' % i])).sum().backward()
+        assert float((x.grad - torch.from_numpy(z['grad_x%d' % i])).abs().max()) < 5e-6
+    # the reference's own facts, utils.py:33-47
+    g = torch.Generator().manual_seed(0)
+    mx = max(float(oo.bicubic_align_corners(torch.rand((1, 1, 8, 8), generator=g) * 2 - 1, (4, 4)).abs().max())
+             for _ in range(1000))
+    assert mx > 1.1                                                    # utils.py:39
+    im0 = torch.tensor([[[[1., -1.], [-1., 1.]]]])
+    assert torch.all(torch.clamp(im0, -1, 1) == im0)                   # utils.py:43
+    im1 = torch.tensor([[[[1.9, -1.], [-1., 1.]]]])
+    assert torch.all(oo.lr_from_hr(im1, (2, 2)) == im0)                # utils.py:47 (identity resize)
+
+
+def test_masked_vgg_topology_known_answers(golden_dir):
+    """get_size known-answers for all 31 masks (model_content_extractor.py:95-104) + values
+    against the torch-primitive stand-in (numerics for pretrained weights: parity unpinned)."""
+    z = np.load(golden_dir + '/vgg_standin.npz')
+    state = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('state/')}
+    div = int(z['width_div'])
+    x = torch.from_numpy(z['x'])
+    assert tuple(i for i, l in enumerate(om.vgg19_feature_layers()) if l[0] == 'pool') == om.MAXPOOL_INDEXES
+    for mask in range(1, 32):
+        f = om.masked_vgg_forward(state, x, mask)
+        assert f.shape == (2, om.get_size((32, 32), mask) // div)       # :101
+    for mask in (0b00010, 0b00011, 0b01111, 0b10000, 0b10101, 0b11111):
+        xg = x.clone().requires_grad_(True)
+        f = om.masked_vgg_forward(state, xg, mask)
+        assert rel_err(f, z['out_%d' % mask]) < TOL
+        (f * torch.from_numpy(z['r_%d' % mask])).sum().backward()
+        assert rel_err(xg.grad, z['grad_x_%d' % mask]) < 1e-4
+    # stale-assert note: len(layers) is 8/8/17 for masks 0b11/0b10/0b110
+    assert [om.masked_vgg_kept(m)[-1] for m in (0b00011, 0b00010, 0b00110)] == [8, 8, 17]
+
+
+def test_losses_match_torch():
+    g = torch.Generator().manual_seed(1)
+    p = torch.rand(16, 1, generator=g).clamp(1e-4, 1 - 1e-4)
+    q = torch.rand(16, 1, generator=g).clamp(1e-4, 1 - 1e-4)
+    crit = torch.nn.BCELoss()                                           # config.py:107
+    ref = crit(p.view(-1), torch.full((16,), .9)) + crit(q.view(-1), torch.full((16,), 0.))
+    assert abs(float(ol.adversarial_loss_d(p, [q]) - ref)) < 1e-6
+    assert abs(float(ol.adversarial_loss_g(q) - crit(q.view(-1), torch.full((16,), 1.)))) < 1e-6
+    assert float(ol.bce(torch.zeros(4), 1.0)) == 100.0                  # log clamp
