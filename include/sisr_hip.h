@@ -1,0 +1,225 @@
+/*
+ * sisr_hip.h -- C ABI of libsisr_hip.so: the MI355X (gfx950) kernels behind the SRGAN hot path
+ * of keyber/Single-Image-Super-Resolution.
+ *
+ * The reference has no FFI of its own: its boundary is the Python nn.Module API
+ * (model_generator.py:22-141, model_discriminator.py:18-76, model_content_extractor.py:33-60,
+ * utils.py:16-31) and every FLOP runs inside torch.nn primitives.  Each entry point below
+ * replaces the torch primitive call sites listed next to it; the Python host side
+ * (single-image-super-resolution_amd/) binds them with ctypes and re-creates the reference's
+ * module interface on top.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless named host_*;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), allocates nothing,
+ *     and returns 0 on success or a hipError_t / negative SISR_E* code; it never aborts;
+ *   - activations are NHWC fp32 inside the path; NCHW (the reference's layout) is accepted on the
+ *     3-channel image side and produced on the RGB / feature-tap side by layout flags;
+ *   - descriptors are filled by the caller for geometry, then completed by the matching
+ *     *_plan() call which chooses the tiling and reports workspace sizes.
+ */
+#ifndef SISR_HIP_H
+#define SISR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SISR_E_BADARG (-1)
+#define SISR_E_TOOBIG (-2)
+#define SISR_E_UNSUPPORTED (-3)
+
+/* ---- input-operand ("prologue") modes: the value fed to the contraction for input element
+ *      (n,iy,ix,c); x1/x2 share shape and layout; out-of-image taps contribute 0. ------------- */
+enum {
+    SISR_PRO_NONE = 0,        /* v = x1                                                        */
+    SISR_PRO_ACT = 1,         /* v = lrelu(x1, slope)            PReLU / LeakyReLU / ReLU       */
+    SISR_PRO_AFFINE_ACT = 2,  /* v = lrelu(pa[c]*x1 + pd[c], slope)   BatchNorm apply + act     */
+    SISR_PRO_BNBWD = 3,       /* v = pa[c]*x1 + pb[c]*x2 + pd[c]      BatchNorm backward        */
+    SISR_PRO_BNACT_BWD = 4,   /* z = ps[c]*x2+pt[c]; g = z>0 ? x1 : slope*x1;
+                                 v = pa[c]*g + pb[c]*x2 + pd[c]       act' then BatchNorm bwd   */
+    SISR_PRO_ACT_BWD = 5,     /* v = x2>0 ? x1 : slope*x1             act' (x2 = pre-activation)*/
+    SISR_PRO_TANH_BWD = 6     /* v = x1*(1 - x2*x2)                   tanh' (x2 = tanh output)  */
+};
+enum { SISR_X_NHWC = 0, SISR_X_NCHW = 1, SISR_X_NHWC_UNSHUFFLE2 = 2 };
+enum { SISR_Y_NHWC = 0, SISR_Y_NCHW = 1, SISR_Y_NHWC_SHUFFLE2 = 2 };
+enum { SISR_EPI_NONE = 0, SISR_EPI_TANH = 1 };
+
+/* Packed-weight layout shared by conv / wgrad / weight kernels:
+ *   wpk[chunk][r][co][krow], krow = s*PS + (ci - chunk*CK), row length KROWP (zero padded),
+ *   co < CoutPad (zero padded).  PS = CK|1 keeps LDS reads conflict-free. */
+typedef struct SisrConvPlan {
+    int32_t TH, TW, TN;             /* output tile: TN images x TH x TW pixels               */
+    int32_t tiles_y, tiles_x, n_groups, n_tiles;
+    int32_t CK, PS, KROWP, n_chunk, CoutPad;
+    int32_t msub, nsub;             /* 32x32 MFMA sub-tiles per wave (M) / per block (N)     */
+    int32_t lds_bytes;
+    int32_t wpk_elems;              /* floats in the packed weight buffer                    */
+} SisrConvPlan;
+
+/* Direct convolution, fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32) accumulate.
+ * Replaces nn.Conv2d forward and its data-gradient (model_generator.py:10,13,33,39,45,52,123;
+ * model_discriminator.py:10,39; torchvision VGG19 convs via model_content_extractor.py:43) with
+ * the neighbouring BatchNorm2d-apply / PReLU / LeakyReLU / ReLU (prologue), bias, Tanh,
+ * PixelShuffle(2) and residual add (epilogue) and the BatchNorm batch statistics fused in. */
+typedef struct SisrConvDesc {
+    const float *x1, *x2;                    /* input operand(s)                              */
+    const float *pa, *pb, *pd, *ps, *pt;     /* per-input-channel prologue constants          */
+    const float *wpk;                        /* packed weights (see above)                    */
+    const float *bias;                       /* [Cout] in ORIGINAL channel order, or NULL     */
+    const float *res;                        /* residual, same layout as y, or NULL           */
+    float *y;
+    float *stat_part;                        /* [n_tiles][2][Cout] (mean, M2) or NULL         */
+    float *cnt_part;                         /* [n_tiles] valid pixels per tile               */
+    int32_t N, H, W, Cin;                    /* logical input                                 */
+    int32_t Ho, Wo, Cout;                    /* logical output grid                           */
+    int32_t KH, KW, stride, pad_y, pad_x;
+    int32_t x_mode, pro_mode;
+    const float *pro_slope_p;                /* device scalar slope (PReLU weight); NULL: pro_slope */
+    float pro_slope;
+    int32_t y_mode, epi_act;
+    int32_t y_sy, y_oy, y_sx, y_ox, y_H, y_W; /* output pixel (oy*y_sy+y_oy, ox*y_sx+y_ox) of a
+                                                y_H x y_W image (strided scatter for the data
+                                                gradient of stride-2 convs); plain: 1,0,1,0,Ho,Wo */
+    SisrConvPlan plan;
+} SisrConvDesc;
+
+int sisr_conv2d_plan(SisrConvDesc *d);                        /* host only: fills d->plan     */
+int sisr_conv2d_f32(const SisrConvDesc *d, void *stream);
+
+/* Weight gradient of the same convolution: dW[r][s][ci][co] = sum_pix in(pix+tap)[ci]*dy(pix)[co].
+ * Replaces the weight/bias part of convolution_backward for the call sites above.  The input
+ * operand (x*, p*, x_mode, pro_*) and the output-gradient operand (g*, q*, g_mode, gpro_*) take
+ * the same prologue modes.  Each block writes one fp32 partial slab; sisr_wgrad_reduce sums them. */
+typedef struct SisrWgradDesc {
+    const float *x1, *x2, *pa, *pb, *pd, *ps, *pt;   /* conv-input operand                    */
+    const float *g1, *g2, *qa, *qb, *qd, *qs, *qt;   /* output-gradient operand               */
+    float *slab;            /* [n_slabs][slab_stride]: packed dW, layout [chunk][r][krow][co]       */
+    float *bias_slab;       /* per-slab bias partial [CoutPad] at the same slab_stride, or NULL
+                               (normally slab + slab_elems, slab_stride = slab_elems + CoutPad)    */
+    int32_t N, H, W, Cin, Ho, Wo, Cout;
+    int32_t KH, KW, stride, pad_y, pad_x;
+    int32_t x_mode, pro_mode;
+    const float *pro_slope_p;
+    float pro_slope;
+    int32_t g_mode, gpro_mode;
+    const float *gpro_slope_p;
+    float gpro_slope;
+    /* plan (filled by sisr_wgrad_plan) */
+    int32_t TH, TW, TN, tiles_y, tiles_x, n_groups, n_tiles;
+    int32_t CK, PS, KROWP, n_chunk, CoutPad;
+    int32_t NJ, NP, NT, TSTEP, TVALID;       /* co sub-tiles, pixel parts, row tiles          */
+    int32_t grid_x, n_slabs, slab_elems, lds_bytes;
+    int64_t slab_stride;                     /* set by the caller after planning              */
+} SisrWgradDesc;
+
+int sisr_wgrad_plan(SisrWgradDesc *d, int32_t max_pixel_blocks);
+int sisr_conv2d_wgrad_f32(const SisrWgradDesc *d, void *stream);
+/* out[i] = sum_s slab[s][i], i < elems (also used for the bias slabs) */
+int sisr_slab_reduce_f32(const float *slab, float *out, int32_t n_slabs, int64_t elems, void *stream);
+
+/* ---- weights: spectral norm power iteration + packing (legacy torch.nn.utils.spectral_norm
+ *      hook, model_generator.py:3; model_discriminator.py:2), multi-tensor: one launch serves
+ *      every convolution of a network.  The descriptor TABLE lives in device memory. ---------- */
+typedef struct SisrWeightDesc {
+    const float *w_orig;      /* OIHW [Cout][Cin][KH][KW]                                     */
+    float *u, *v;             /* spectral-norm buffers (updated in place when training) or NULL */
+    float *u_used, *v_used;   /* copies of the u/v that define sigma (for backward) or NULL   */
+    float *sigma;             /* [1] out (1.0 when u == NULL)                                 */
+    float *wpk_fwd;           /* packed W/sigma for the forward conv, or NULL                 */
+    float *wpk_dgrad;         /* packed flipped/transposed W/sigma for the data gradient, or NULL */
+    int32_t Cout, Cin, KH, KW;
+    int32_t training;         /* run the power iteration                                      */
+    int32_t shuffle2;         /* conv feeds PixelShuffle(2): pack couts in (i,j)-major order  */
+    /* forward packing */
+    int32_t f_CK, f_PS, f_KROWP, f_n_chunk, f_CoutPad;
+    /* data-gradient packing (roles of Cin/Cout swapped) */
+    int32_t d_CK, d_PS, d_KROWP, d_n_chunk, d_CoutPad;
+} SisrWeightDesc;
+
+int sisr_weights_prepare(const SisrWeightDesc *table_dev, int32_t n, void *stream);
+
+/* Weight-gradient epilogue: packed dW (sum of slabs) -> OIHW gradient of w_orig, through the
+ * spectral-norm quotient: dW_orig = (G - <G, W> u v^T) / sigma  (autograd of W = W_orig/sigma with
+ * sigma = u.(W_mat v), u and v constant; spectral_norm.py compute_weight). */
+typedef struct SisrWeightGradDesc {
+    const float *dwpk;        /* [chunk][r][krow][CoutPad] reduced packed gradient            */
+    const float *w_orig, *u_used, *v_used, *sigma;   /* u_used == NULL: no spectral norm      */
+    float *grad;              /* OIHW out                                                     */
+    const float *dbias_pk;    /* [CoutPad] reduced packed bias gradient or NULL               */
+    float *grad_bias;         /* [Cout] out (original channel order) or NULL                  */
+    int32_t Cout, Cin, KH, KW, shuffle2;
+    int32_t CK, PS, KROWP, n_chunk, CoutPad;
+} SisrWeightGradDesc;
+
+int sisr_weights_grad(const SisrWeightGradDesc *table_dev, int32_t n, void *stream);
+
+/* ---- BatchNorm2d (training) pieces that are not fused into the convolutions ------------------
+ * finalize: merge the per-tile (mean, M2) partials (Chan et al.), produce the fused apply
+ * constants scale = gamma*invstd, shift = beta - mean*scale, update the running statistics
+ * (momentum 0.1, unbiased variance) -- nn.BatchNorm2d, model_generator.py:11,14,40. */
+int sisr_bn_finalize(const float *stat_part, const float *cnt_part, int32_t n_tiles, int32_t C,
+                     const float *gamma, const float *beta, float *running_mean, float *running_var,
+                     float momentum, float eps, float *scale, float *shift, float *save_mean,
+                     float *save_invstd, void *stream);
+/* eval mode: scale/shift from the running statistics */
+int sisr_bn_eval_consts(const float *gamma, const float *beta, const float *running_mean,
+                        const float *running_var, float eps, int32_t C, float *scale, float *shift,
+                        void *stream);
+
+/* backward reductions over N*H*W for one BatchNorm (+ the activation that follows it):
+ *   g  = (act_mode ? (z>0 ? dy : slope*dy) : dy),  z = scale[c]*x + shift[c]
+ *   sum_g[c] = sum g ; sum_gx[c] = sum g*xhat,  xhat = (x-mean[c])*invstd[c]
+ *   sum_slope = sum over z<=0 of dy*z   (gradient of a shared PReLU slope)
+ * then the constants of SISR_PRO_BNBWD / SISR_PRO_BNACT_BWD:
+ *   qa = gamma*invstd ; qb = -gamma*invstd^2*mean(g*xhat) ; qd = -qa*mean(g) - qb*mean
+ * and dgamma = sum_gx, dbeta = sum_g, dslope (if act). */
+typedef struct SisrBnBwdDesc {
+    const float *dy, *x;                   /* NHWC [P][C]                                    */
+    const float *scale, *shift, *mean, *invstd, *gamma;
+    float *work;                           /* [grid][2*C+1] partials                          */
+    float *qa, *qb, *qd;                   /* out [C]                                         */
+    float *dgamma, *dbeta, *dslope;        /* out [C],[C],[1] (dslope may be NULL)            */
+    int64_t P; int32_t C;
+    int32_t act_mode;
+    const float *slope_p; float slope;     /* device scalar slope, or NULL: use `slope`       */
+    int32_t grid;                          /* filled by sisr_bn_bwd_plan                      */
+} SisrBnBwdDesc;
+int sisr_bn_bwd_plan(SisrBnBwdDesc *d);
+int sisr_bn_bwd(const SisrBnBwdDesc *d, void *stream);
+
+/* elementwise: y = f(x1) + (pa ? pa[c]*x2 + pd[c] : x2)   over NHWC [P][C];
+ * f = lrelu(., slope1_p ? *slope1_p : slope1) -- the residual add of BasicBlock.forward (model_generator.py:19) and the
+ * long skip (model_generator.py:93) with the BatchNorm apply fused.  x2 may be NULL (y = f(x1)). */
+int sisr_eltwise_res_affine(const float *x1, const float *slope1_p, float slope1, const float *x2,
+                            const float *pa, const float *pd, float *y, int64_t P, int32_t C,
+                            void *stream);
+/* sum over all elements where pre<=0 of dy*pre  -> out[0]  (gradient of a PReLU slope that is
+ * not followed by... BatchNorm-free sites: model_generator.py:34,48) ; work: [grid] floats */
+int sisr_prelu_slope_grad(const float *dy, const float *pre, int64_t n, float *work, float *out,
+                          void *stream);
+/* y = a + b (same shape) */
+int sisr_add(const float *a, const float *b, float *y, int64_t n, void *stream);
+
+/* ---- bicubic degradation, align_corners=True, A=-0.75, clamp to [-1,1]
+ *      (utils.py:16-31: F.interpolate(..., 'bicubic', align_corners=True) + _crop_lr) -------- */
+int sisr_bicubic_fwd(const float *x, float *y, int32_t NC, int32_t H, int32_t W, int32_t Ho,
+                     int32_t Wo, int32_t clamp, void *stream);
+/* dx += / = transpose of the interpolation applied to dy (masked by the clamp when y given) */
+int sisr_bicubic_bwd(const float *dy, const float *y_clamped, float *dx, int32_t NC, int32_t H,
+                     int32_t W, int32_t Ho, int32_t Wo, void *stream);
+
+/* ---- misc ---------------------------------------------------------------------------------- */
+/* sizeof() of the descriptor structs in declaration order (Conv, Wgrad, Weight, WeightGrad,
+ * BnBwd, ConvPlan) so a binding can verify its mirror of this header; returns the count. */
+int sisr_struct_sizes(int32_t *out, int32_t cap);
+int sisr_device_info(int32_t *n_cu, int32_t *lds_per_cu, char *arch, int32_t arch_len);
+int sisr_mfma_selftest(float *out_dev /* >= 32*32 floats */, void *stream);
+const char *sisr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SISR_HIP_H */

@@ -61,12 +61,12 @@ def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.
 
 def prelu(x, a):
     """nn.PReLU() with ONE shared scalar slope (model_generator.py:12,34,48,59,126)."""
-    return torch.clamp(x, min=0) + a * torch.clamp(x, max=0)
+    return torch.where(x > 0, x, a * x)
 
 
 def leaky_relu(x, slope=0.01):
     """nn.LeakyReLU() default slope 0.01 (model_discriminator.py:12,40,50)."""
-    return torch.clamp(x, min=0) + slope * torch.clamp(x, max=0)
+    return torch.where(x > 0, x, slope * x)
 
 
 def pixel_shuffle(x, r):

@@ -1,0 +1,142 @@
+"""ctypes binding of libsisr_hip.so (C ABI: include/sisr_hip.h).
+
+The library is the product: there is NO CPU or eager-PyTorch fallback.  If it is missing or does
+not match this mirror of the header, importing the hot path raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libsisr_hip.so')
+
+# enums (sisr_hip.h)
+PRO_NONE, PRO_ACT, PRO_AFFINE_ACT, PRO_BNBWD, PRO_BNACT_BWD, PRO_ACT_BWD, PRO_TANH_BWD = range(7)
+X_NHWC, X_NCHW, X_UNSHUFFLE2 = range(3)
+Y_NHWC, Y_NCHW, Y_SHUFFLE2 = range(3)
+EPI_NONE, EPI_TANH = range(2)
+
+_f = C.c_void_p      # device pointers travel as void*
+_i32 = C.c_int32
+_i64 = C.c_int64
+_f32 = C.c_float
+
+
+class ConvPlan(C.Structure):
+    _fields_ = [(n, _i32) for n in (
+        'TH', 'TW', 'TN', 'tiles_y', 'tiles_x', 'n_groups', 'n_tiles', 'CK', 'PS', 'KROWP', 'n_chunk',
+        'CoutPad', 'msub', 'nsub', 'lds_bytes', 'wpk_elems')]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = ([(n, _f) for n in ('x1', 'x2', 'pa', 'pb', 'pd', 'ps', 'pt', 'wpk', 'bias', 'res', 'y',
+                                   'stat_part', 'cnt_part')] +
+                [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride',
+                                     'pad_y', 'pad_x', 'x_mode', 'pro_mode')] +
+                [('pro_slope_p', _f), ('pro_slope', _f32)] +
+                [(n, _i32) for n in ('y_mode', 'epi_act', 'y_sy', 'y_oy', 'y_sx', 'y_ox', 'y_H', 'y_W')] +
+                [('plan', ConvPlan)])
+
+
+class WgradDesc(C.Structure):
+    _fields_ = ([(n, _f) for n in ('x1', 'x2', 'pa', 'pb', 'pd', 'ps', 'pt',
+                                   'g1', 'g2', 'qa', 'qb', 'qd', 'qs', 'qt', 'slab', 'bias_slab')] +
+                [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride',
+                                     'pad_y', 'pad_x', 'x_mode', 'pro_mode')] +
+                [('pro_slope_p', _f), ('pro_slope', _f32), ('g_mode', _i32), ('gpro_mode', _i32),
+                 ('gpro_slope_p', _f), ('gpro_slope', _f32)] +
+                [(n, _i32) for n in ('TH', 'TW', 'TN', 'tiles_y', 'tiles_x', 'n_groups', 'n_tiles',
+                                     'CK', 'PS', 'KROWP', 'n_chunk', 'CoutPad',
+                                     'NJ', 'NP', 'NT', 'TSTEP', 'TVALID',
+                                     'grid_x', 'n_slabs', 'slab_elems', 'lds_bytes')] +
+                [('slab_stride', _i64)])
+
+
+class WeightDesc(C.Structure):
+    _fields_ = ([(n, _f) for n in ('w_orig', 'u', 'v', 'u_used', 'v_used', 'sigma', 'wpk_fwd', 'wpk_dgrad')] +
+                [(n, _i32) for n in ('Cout', 'Cin', 'KH', 'KW', 'training', 'shuffle2',
+                                     'f_CK', 'f_PS', 'f_KROWP', 'f_n_chunk', 'f_CoutPad',
+                                     'd_CK', 'd_PS', 'd_KROWP', 'd_n_chunk', 'd_CoutPad')])
+
+
+class WeightGradDesc(C.Structure):
+    _fields_ = ([(n, _f) for n in ('dwpk', 'w_orig', 'u_used', 'v_used', 'sigma', 'grad', 'dbias_pk',
+                                   'grad_bias')] +
+                [(n, _i32) for n in ('Cout', 'Cin', 'KH', 'KW', 'shuffle2', 'CK', 'PS', 'KROWP', 'n_chunk',
+                                     'CoutPad')])
+
+
+class BnBwdDesc(C.Structure):
+    _fields_ = ([(n, _f) for n in ('dy', 'x', 'scale', 'shift', 'mean', 'invstd', 'gamma', 'work',
+                                   'qa', 'qb', 'qd', 'dgamma', 'dbeta', 'dslope')] +
+                [('P', _i64), ('C', _i32), ('act_mode', _i32), ('slope_p', _f), ('slope', _f32),
+                 ('grid', _i32)])
+
+
+_SIGS = {
+    'sisr_conv2d_plan': [C.POINTER(ConvDesc)],
+    'sisr_conv2d_f32': [C.POINTER(ConvDesc), _f],
+    'sisr_wgrad_plan': [C.POINTER(WgradDesc), _i32],
+    'sisr_conv2d_wgrad_f32': [C.POINTER(WgradDesc), _f],
+    'sisr_slab_reduce_f32': [_f, _f, _i32, _i64, _f],
+    'sisr_weights_prepare': [_f, _i32, _f],
+    'sisr_weights_grad': [_f, _i32, _f],
+    'sisr_bn_finalize': [_f, _f, _i32, _i32, _f, _f, _f, _f, _f32, _f32, _f, _f, _f, _f, _f],
+    'sisr_bn_eval_consts': [_f, _f, _f, _f, _f32, _i32, _f, _f, _f],
+    'sisr_bn_bwd_plan': [C.POINTER(BnBwdDesc)],
+    'sisr_bn_bwd': [C.POINTER(BnBwdDesc), _f],
+    'sisr_eltwise_res_affine': [_f, _f, _f32, _f, _f, _f, _f, _i64, _i32, _f],
+    'sisr_prelu_slope_grad': [_f, _f, _i64, _f, _f, _f],
+    'sisr_add': [_f, _f, _f, _i64, _f],
+    'sisr_bicubic_fwd': [_f, _f, _i32, _i32, _i32, _i32, _i32, _i32, _f],
+    'sisr_bicubic_bwd': [_f, _f, _f, _i32, _i32, _i32, _i32, _i32, _f],
+    'sisr_struct_sizes': [C.POINTER(_i32), _i32],
+    'sisr_device_info': [C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32],
+    'sisr_mfma_selftest': [_f, _f],
+}
+EXPORTS = sorted(list(_SIGS) + ['sisr_version'])
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    r = subprocess.run(['make', '-C', CSRC, '-j8'], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise RuntimeError('building libsisr_hip.so failed (hipcc --offload-arch=gfx950)')
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library.  Raises RuntimeError if it is absent or mismatched -- no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'libsisr_hip.so not found at %s: the MI355X HIP library IS the implementation of this '
+            'path (no CPU/eager fallback). Build it with `python __graft_entry__.py build` or '
+            '`make -C %s`.' % (LIB_PATH, CSRC))
+    L = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    L.sisr_version.restype = C.c_char_p
+    L.sisr_version.argtypes = []
+    sizes = (_i32 * 8)()
+    n = L.sisr_struct_sizes(sizes, 8)
+    mine = [C.sizeof(t) for t in (ConvDesc, WgradDesc, WeightDesc, WeightGradDesc, BnBwdDesc, ConvPlan)]
+    if n != 6 or list(sizes[:6]) != mine:
+        raise RuntimeError('libsisr_hip.so does not match the Python mirror of sisr_hip.h: %s vs %s'
+                           % (list(sizes[:6]), mine))
+    _lib = L
+    return L
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError('%s failed with status %d' % (what, status))

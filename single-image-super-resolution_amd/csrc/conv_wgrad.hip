@@ -1,0 +1,232 @@
+// conv_wgrad.hip -- weight gradient of the direct convolution on gfx950 (fp32, exact-fp32 MFMA).
+//
+//   dW[r][s][ci][co] = sum over output pixels p of  in(p*stride + (r,s) - pad)[ci] * dy(p)[co]
+//
+// GEMM view per filter row r: rows i = contiguous K-row index (s*PS + ci) of the LDS input tile
+// (same [pixel][PS] image as conv_fwd.hip), columns j = co, contraction over PIXELS (2 per
+// v_mfma_f32_32x32x2_f32).  A workgroup owns one (channel chunk, cout tile) and walks pixel tiles
+// grid-stride with all KH*NT accumulators (<= 9 x 16 VGPRs) resident, so the input tile is read
+// from HBM once for all taps.  Wave w = (jsub = w % NJ : its 32 couts, ppart = w / NJ : its share
+// of the tile's pixel rows); parts are summed through LDS and every workgroup writes ONE partial
+// slab, reduced by sisr_slab_reduce_f32 (deterministic, no atomics).  Both operands take the lazy
+// prologues of sisr_hip.h, e.g. in = PReLU(BN(c_prev)) and dy = BatchNorm-backward(g, c).
+// Replaces the weight/bias half of convolution_backward for the nn.Conv2d call sites listed in
+// conv_fwd.hip.
+#include "sisr_dev.h"
+
+#include <algorithm>
+#include <cstring>
+
+#define WG_NACC 9
+
+__global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_f32_kernel(const SisrWgradDesc d) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int S = d.stride;
+    const int TWp = (d.TW + 1) & ~1;
+    const int IH = (d.TH - 1) * S + d.KH, IW = (TWp - 1) * S + d.KW;
+    const int in_elems = d.TN * IH * IW * d.PS;
+    const int DSTR = d.NJ * 32;
+    const int NP = 4 / d.NJ;
+    const int jsub = wave % d.NJ, ppart = wave / d.NJ;
+    const int q = blockIdx.y % d.n_chunk, cot = blockIdx.y / d.n_chunk;
+    const int co_base = cot * DSTR;
+    const int nacc = d.KH * d.NT;
+
+    float* lds_in = smem;
+    float* lds_dy = smem + ((in_elems + 64 + 3) & ~3);
+
+    OperandView ox, og;
+    ox.x1 = d.x1; ox.x2 = d.x2; ox.pa = d.pa; ox.pb = d.pb; ox.pd = d.pd; ox.ps = d.ps; ox.pt = d.pt;
+    ox.N = d.N; ox.H = d.H; ox.W = d.W; ox.C = d.Cin; ox.mode = d.x_mode; ox.pro = d.pro_mode;
+    ox.slope = d.pro_slope_p ? d.pro_slope_p[0] : d.pro_slope;
+    og.x1 = d.g1; og.x2 = d.g2; og.pa = d.qa; og.pb = d.qb; og.pd = d.qd; og.ps = d.qs; og.pt = d.qt;
+    og.N = d.N; og.H = d.Ho; og.W = d.Wo; og.C = d.Cout; og.mode = d.g_mode; og.pro = d.gpro_mode;
+    og.slope = d.gpro_slope_p ? d.gpro_slope_p[0] : d.gpro_slope;
+    const bool xvec = (d.x_mode != SISR_X_NCHW) && !(d.CK & 3) && !(d.Cin & 3) &&
+                      !(d.x_mode == SISR_X_NHWC_UNSHUFFLE2 && ((d.Cin >> 2) & 3));
+    const bool gvec = (d.g_mode != SISR_X_NCHW) && !(d.Cout & 3) &&
+                      !(d.g_mode == SISR_X_NHWC_UNSHUFFLE2 && ((d.Cout >> 2) & 3));
+
+    int aoff[WG_NACC];
+#pragma unroll
+    for (int a = 0; a < WG_NACC; ++a) {
+        const int r = a / d.NT, tt = a - r * d.NT;
+        aoff[a] = r * IW * d.PS + tt * d.TSTEP;
+    }
+    f32x16 acc[WG_NACC];
+#pragma unroll
+    for (int a = 0; a < WG_NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+    float bias_acc = 0.f;
+
+    for (int t = blockIdx.x; t < d.n_tiles; t += gridDim.x) {
+        int tt_ = t;
+        const int txi = tt_ % d.tiles_x;
+        tt_ /= d.tiles_x;
+        const int tyi = tt_ % d.tiles_y, ng = tt_ / d.tiles_y;
+        const int n0 = ng * d.TN, oy0 = tyi * d.TH, ox0 = txi * d.TW;
+        __syncthreads();   // previous tile fully consumed
+        stage_operand_tile(ox, lds_in, d.PS, d.CK, q * d.CK, d.TN, IH, IW, n0, oy0 * S - d.pad_y,
+                           ox0 * S - d.pad_x, xvec, 1 << 30, 64);
+        // dy tile: TN x TH x TWp pixels, channels [co_base, co_base + DSTR); columns >= TW are zero
+        stage_operand_tile(og, lds_dy, DSTR, DSTR, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, gvec, d.TW, 0);
+        __syncthreads();
+        if (d.bias_slab != nullptr && q == 0 && tid < DSTR) {
+            const int npx = d.TN * d.TH * TWp;
+            float s = 0.f;
+            for (int px = 0; px < npx; ++px) s += lds_dy[px * DSTR + tid];
+            bias_acc += s;
+        }
+        const int nrows = d.TN * d.TH;
+        for (int row = ppart; row < nrows; row += NP) {
+            const int tn = row / d.TH, ty = row - tn * d.TH;
+            const float* dyp = lds_dy + (row * TWp + kk) * DSTR + jsub * 32 + l31;
+            const float* inp = lds_in + ((tn * IH + ty * S) * IW + kk * S) * d.PS + l31;
+            for (int tx0 = 0; tx0 < TWp; tx0 += 2) {
+                const float bval = dyp[tx0 * DSTR];
+                const float* ip = inp + tx0 * S * d.PS;
+#pragma unroll
+                for (int a = 0; a < WG_NACC; ++a) {
+                    if (a < nacc) acc[a] = mfma32(ip[aoff[a]], bval, acc[a]);
+                }
+            }
+        }
+    }
+
+    // ---- sum the pixel parts of each jsub through LDS (one round per extra part) -----------------
+    __syncthreads();
+    for (int k = 1; k < NP; ++k) {
+        float* buf = smem + (size_t)jsub * (WG_NACC * 16 * 64);
+        if (ppart == k) {
+#pragma unroll
+            for (int a = 0; a < WG_NACC; ++a)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) buf[(a * 16 + i) * 64 + lane] = acc[a][i];
+        }
+        __syncthreads();
+        if (ppart == 0) {
+#pragma unroll
+            for (int a = 0; a < WG_NACC; ++a)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][i] += buf[(a * 16 + i) * 64 + lane];
+        }
+        __syncthreads();
+    }
+
+    if (ppart == 0) {
+        float* sl = d.slab + (int64_t)blockIdx.x * d.slab_stride;
+        const int kvalid = d.KW * d.PS;
+#pragma unroll
+        for (int a = 0; a < WG_NACC; ++a) {
+            if (a >= nacc) continue;
+            const int r = a / d.NT, tt = a - r * d.NT;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = mfma_row(i, lane);
+                const int krow = tt * d.TSTEP + row;
+                if (row < d.TVALID && krow < kvalid)
+                    sl[((int64_t)(q * d.KH + r) * d.KROWP + krow) * d.CoutPad + co_base + jsub * 32 + l31] =
+                        acc[a][i];
+            }
+        }
+    }
+    if (d.bias_slab != nullptr && q == 0 && tid < DSTR)
+        d.bias_slab[(int64_t)blockIdx.x * d.slab_stride + co_base + tid] = bias_acc;
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int n_slabs,
+                                   int64_t elems) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < n_slabs; ++k) s += slab[(int64_t)k * elems + i];
+        out[i] = s;
+    }
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" int sisr_wgrad_plan(SisrWgradDesc* d, int32_t max_pixel_blocks) {
+    if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0) return SISR_E_BADARG;
+    if (d->stride != 1 && d->stride != 2) return SISR_E_BADARG;
+    d->CK = d->Cin <= 32 ? d->Cin : 32;
+    d->PS = d->CK | 1;
+    d->KROWP = round_up(d->KW * d->PS, 4);
+    d->n_chunk = (d->Cin + d->CK - 1) / d->CK;
+    if (d->CK == 32) { d->NT = d->KW; d->TSTEP = d->PS; d->TVALID = 32; }
+    else { d->NT = (d->KW * d->PS + 31) / 32; d->TSTEP = 32; d->TVALID = 32; }
+    if (d->KH * d->NT > WG_NACC) return SISR_E_UNSUPPORTED;
+    const int c32 = round_up(d->Cout, 32) / 32;
+    d->NJ = c32 >= 4 ? 4 : (c32 >= 2 ? 2 : 1);
+    d->NP = 4 / d->NJ;
+    d->CoutPad = round_up(d->Cout, d->NJ * 32);
+    const int S = d->stride, DSTR = d->NJ * 32;
+    const int red_bytes = d->NP > 1 ? d->NJ * WG_NACC * 16 * 64 * 4 : 0;
+    double best = -1.0;
+    for (int BMW = 128; BMW >= 32 && best < 0; BMW >>= 1) {
+        for (int TW = 1; TW <= std::min(d->Wo, BMW); ++TW) {
+            const int TWp = (TW + 1) & ~1;
+            const int TH = std::min(d->Ho, BMW / TWp);
+            if (TH < 1) continue;
+            int TN = 1;
+            if (TH == d->Ho && TW == d->Wo) TN = std::max(1, std::min(d->N, BMW / (TH * TWp)));
+            const int IH = (TH - 1) * S + d->KH, IW = (TWp - 1) * S + d->KW;
+            const int in_elems = TN * IH * IW * d->PS;
+            const int lds = std::max((((in_elems + 64 + 3) & ~3) + TN * TH * TWp * DSTR + 8) * 4, red_bytes);
+            if (lds > 80 * 1024) continue;
+            const int ty = (d->Ho + TH - 1) / TH, tx = (d->Wo + TW - 1) / TW, ngr = (d->N + TN - 1) / TN;
+            const double eff = (double)d->N * d->Ho * d->Wo / ((double)ty * tx * ngr * TN * TH * TWp);
+            const double halo = (double)(TH * TW) * S * S / ((double)IH * IW);
+            const double fill = (double)(TN * TH * TWp) / BMW;
+            const double score = eff * (0.7 + 0.3 * halo) * (0.8 + 0.2 * fill);
+            if (score > best + 1e-9) {
+                best = score;
+                d->TH = TH; d->TW = TW; d->TN = TN; d->tiles_y = ty; d->tiles_x = tx; d->n_groups = ngr;
+                d->lds_bytes = lds;
+            }
+        }
+    }
+    if (best < 0) return SISR_E_TOOBIG;
+    d->n_tiles = d->tiles_y * d->tiles_x * d->n_groups;
+    const int per_pixel_block = d->n_chunk * (d->CoutPad / DSTR);
+    int gx = std::max(1, max_pixel_blocks / per_pixel_block);
+    d->grid_x = std::min(gx, d->n_tiles);
+    d->n_slabs = d->grid_x;
+    d->slab_elems = d->n_chunk * d->KH * d->KROWP * d->CoutPad;
+    d->slab_stride = d->slab_elems;
+    return 0;
+}
+
+extern "C" int sisr_conv2d_wgrad_f32(const SisrWgradDesc* d, void* stream) {
+    if (!d || !d->x1 || !d->g1 || !d->slab) return SISR_E_BADARG;
+    if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
+    if (operand_needs_x2(d->gpro_mode) && !d->g2) return SISR_E_BADARG;
+    if (d->slab_stride < d->slab_elems) return SISR_E_BADARG;
+    if (d->grid_x <= 0 || d->lds_bytes <= 0 || d->lds_bytes > 160 * 1024 || d->KH * d->NT > WG_NACC)
+        return SISR_E_BADARG;
+    static int lds_max = 64 * 1024;
+    if (d->lds_bytes > lds_max) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_f32_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        lds_max = d->lds_bytes;
+    }
+    const dim3 grid(d->grid_x, d->n_chunk * (d->CoutPad / (d->NJ * 32)));
+    hipLaunchKernelGGL(wgrad_mfma_f32_kernel, grid, dim3(SISR_BLOCK), d->lds_bytes,
+                       reinterpret_cast<hipStream_t>(stream), *d);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_slab_reduce_f32(const float* slab, float* out, int32_t n_slabs, int64_t elems,
+                                    void* stream) {
+    if (!slab || !out || n_slabs <= 0 || elems <= 0) return SISR_E_BADARG;
+    const int blocks = (int)std::min<int64_t>((elems + 255) / 256, 2048);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       slab, out, n_slabs, elems);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,54 @@
+// misc.hip -- device query and an MFMA lane-layout self test (run by the GPU test-suite before any
+// parity test so that a wrong operand/accumulator map is reported as such).
+#include "sisr_dev.h"
+
+#include <cstring>
+
+// C[32][32] = A[32][K=8] * B[8][32] with asymmetric integer data; out row-major [row][col]
+__global__ void mfma_selftest_kernel(float* out) {
+    const int lane = threadIdx.x & 63;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int k0 = 0; k0 < 8; k0 += 2) {
+        const int k = k0 + (lane >> 5);
+        const float a = (float)((lane & 31) * 3 + k * 7 + 1);     // A[i][k] = 3i + 7k + 1
+        const float b = (float)(k * 5 - (lane & 31) * 2 + 11);    // B[k][j] = 5k - 2j + 11
+        acc = mfma32(a, b, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[mfma_row(i, lane) * 32 + (lane & 31)] = acc[i];
+}
+
+extern "C" int sisr_mfma_selftest(float* out_dev, void* stream) {
+    if (!out_dev) return SISR_E_BADARG;
+    hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), out_dev);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_device_info(int32_t* n_cu, int32_t* lds_per_cu, char* arch, int32_t arch_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return (int)e;
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (lds_per_cu) *lds_per_cu = (int32_t)prop.maxSharedMemoryPerMultiProcessor;
+    if (arch && arch_len > 0) {
+        std::strncpy(arch, prop.gcnArchName, arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    return 0;
+}
+
+extern "C" int sisr_struct_sizes(int32_t* out, int32_t cap) {
+    const int32_t v[6] = {(int32_t)sizeof(SisrConvDesc), (int32_t)sizeof(SisrWgradDesc), (int32_t)sizeof(SisrWeightDesc),
+                          (int32_t)sizeof(SisrWeightGradDesc), (int32_t)sizeof(SisrBnBwdDesc),
+                          (int32_t)sizeof(SisrConvPlan)};
+    for (int i = 0; i < 6 && i < cap; ++i) out[i] = v[i];
+    return 6;
+}
+
+extern "C" const char* sisr_version(void) { return "sisr_hip 0.1 (gfx950, fp32 MFMA path)"; }

@@ -1,0 +1,275 @@
+// norm.hip -- BatchNorm2d (training mode) pieces that are not fused into the convolutions, the
+// residual/BatchNorm-apply elementwise pass, and the small reductions of the backward pass.
+// Replaces nn.BatchNorm2d fwd/bwd (model_generator.py:11,14,40; model_discriminator.py:11), the
+// shared-slope nn.PReLU gradient (model_generator.py:12,34,48) and the residual adds
+// (model_generator.py:19,93).  All reductions are deterministic (no atomics): wave shuffles ->
+// LDS -> per-workgroup partials -> a single finishing workgroup.
+#include "sisr_dev.h"
+
+#include <algorithm>
+
+// ---- forward statistics: Chan-merge of the per-tile (count, mean, M2) partials ------------------
+__global__ void __launch_bounds__(SISR_BLOCK) bn_finalize_kernel(
+    const float* __restrict__ stat_part, const float* __restrict__ cnt_part, int n_tiles, int C,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+    float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
+    float* save_invstd) {
+    __shared__ double sh_n[4][64], sh_mean[4][64], sh_m2[4][64];
+    const int cl = threadIdx.x & 63, split = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    if (c < C) {
+        for (int t = split; t < n_tiles; t += 4) {
+            const double nb = cnt_part[t];
+            if (nb <= 0.0) continue;
+            const double mb = stat_part[(int64_t)t * 2 * C + c];
+            const double qb = stat_part[(int64_t)t * 2 * C + C + c];
+            const double nn = n + nb, delta = mb - mean;
+            mean += delta * (nb / nn);
+            m2 += qb + delta * delta * (n * nb / nn);
+            n = nn;
+        }
+    }
+    sh_n[split][cl] = n; sh_mean[split][cl] = mean; sh_m2[split][cl] = m2;
+    __syncthreads();
+    if (split == 0 && c < C) {
+        for (int k = 1; k < 4; ++k) {
+            const double nb = sh_n[k][cl];
+            if (nb <= 0.0) continue;
+            const double nn = n + nb, delta = sh_mean[k][cl] - mean;
+            mean += delta * (nb / nn);
+            m2 += sh_m2[k][cl] + delta * delta * (n * nb / nn);
+            n = nn;
+        }
+        const double var = m2 / n;                       // biased (normalisation)
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        save_mean[c] = (float)mean;
+        save_invstd[c] = invstd;
+        const double unb = n > 1.0 ? m2 / (n - 1.0) : var;   // unbiased (running estimate)
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_eval_consts_kernel(const float* gamma, const float* beta, const float* rm,
+                                      const float* rv, float eps, int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sc = gamma[c] / sqrtf(rv[c] + eps);
+        scale[c] = sc;
+        shift[c] = beta[c] - rm[c] * sc;
+    }
+}
+
+// ---- backward reductions ------------------------------------------------------------------------
+// thread = (channel group of 4, pixel lane); workgroup partials work[blk][2*C+1]
+__global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_reduce_kernel(const SisrBnBwdDesc d) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // [PL][2*C + PLpad]
+    __shared__ float scratch[8];
+    const int G = d.C >> 2, PL = SISR_BLOCK / G;
+    const int g = threadIdx.x % G, pl = threadIdx.x / G;
+    const int c = g * 4;
+    f32x4 sc, sf, mu, is;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sc[j] = d.scale[c + j]; sf[j] = d.shift[c + j]; mu[j] = d.mean[c + j]; is[j] = d.invstd[c + j];
+    }
+    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
+    float ssl = 0.f;
+    const float slope = d.slope_p ? d.slope_p[0] : d.slope;
+    for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < d.P; p += (int64_t)gridDim.x * PL) {
+        const f32x4 dy = *reinterpret_cast<const f32x4*>(d.dy + p * d.C + c);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(d.x + p * d.C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gg = dy[j];
+            if (d.act_mode) {
+                const float z = sc[j] * x[j] + sf[j];
+                if (!(z > 0.f)) { ssl += dy[j] * z; gg = slope * dy[j]; }
+            }
+            sg[j] += gg;
+            sgx[j] += gg * ((x[j] - mu[j]) * is[j]);
+        }
+    }
+    // reduce over the PL pixel lanes through LDS
+    float* a = sh;   // [PL][2*C]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[pl * 2 * d.C + c + j] = sg[j];
+        a[pl * 2 * d.C + d.C + c + j] = sgx[j];
+    }
+    const float tot_sl = block_sum(ssl, scratch);   // contains the barrier that publishes `a`
+    float* wk = d.work + (int64_t)blockIdx.x * (2 * d.C + 1);
+    for (int i = threadIdx.x; i < 2 * d.C; i += SISR_BLOCK) {
+        float s = 0.f;
+        for (int k = 0; k < PL; ++k) s += a[k * 2 * d.C + i];
+        wk[i] = s;
+    }
+    if (threadIdx.x == 0) wk[2 * d.C] = tot_sl;
+}
+
+__global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_finalize_kernel(const SisrBnBwdDesc d) {
+    __shared__ float scratch[8];
+    const int stride = 2 * d.C + 1;
+    const double inv_n = 1.0 / (double)d.P;
+    for (int c = threadIdx.x; c < d.C; c += SISR_BLOCK) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = 0; b < d.grid; ++b) {
+            s1 += d.work[(int64_t)b * stride + c];
+            s2 += d.work[(int64_t)b * stride + d.C + c];
+        }
+        const float ga = d.gamma[c], is = d.invstd[c], mu = d.mean[c];
+        const float qa = ga * is;
+        const float qb = (float)(-(double)ga * is * is * (s2 * inv_n));
+        d.qa[c] = qa;
+        d.qb[c] = qb;
+        d.qd[c] = (float)(-(double)qa * (s1 * inv_n)) - qb * mu;
+        d.dgamma[c] = (float)s2;
+        d.dbeta[c] = (float)s1;
+    }
+    if (d.dslope != nullptr) {
+        float part = 0.f;
+        for (int b = threadIdx.x; b < d.grid; b += SISR_BLOCK) part += d.work[(int64_t)b * stride + 2 * d.C];
+        const float tot = block_sum(part, scratch);
+        if (threadIdx.x == 0) d.dslope[0] = tot;
+    }
+}
+
+// ---- elementwise --------------------------------------------------------------------------------
+__global__ void eltwise_res_affine_kernel(const float* __restrict__ x1, const float* slope1_p, float slope1,
+                                          const float* __restrict__ x2, const float* __restrict__ pa,
+                                          const float* __restrict__ pd, float* __restrict__ y,
+                                          int64_t n4, int C) {
+    if (slope1_p != nullptr) slope1 = slope1_p[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(x1)[i];
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = lrelu(a[j], slope1);
+        if (x2 != nullptr) {
+            const f32x4 b = reinterpret_cast<const f32x4*>(x2)[i];
+            if (pa != nullptr) {
+                const int c = (int)((i * 4) % C);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] += pa[c + j] * b[j] + pd[c + j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] += b[j];
+            }
+        }
+        reinterpret_cast<f32x4*>(y)[i] = r;
+    }
+}
+
+__global__ void __launch_bounds__(SISR_BLOCK) prelu_slope_partial_kernel(const float* __restrict__ dy,
+                                                                         const float* __restrict__ pre,
+                                                                         int64_t n, float* work) {
+    __shared__ float scratch[8];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * SISR_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SISR_BLOCK) {
+        const float p = pre[i];
+        if (!(p > 0.f)) s += dy[i] * p;
+    }
+    const float t = block_sum(s, scratch);
+    if (threadIdx.x == 0) work[blockIdx.x] = t;
+}
+
+__global__ void __launch_bounds__(SISR_BLOCK) sum_partials_kernel(const float* work, int n, float* out) {
+    __shared__ float scratch[8];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += SISR_BLOCK) s += work[i];
+    const float t = block_sum(s, scratch);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                           int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = a[i] + b[i];
+}
+
+// ---- C ABI ----------------------------------------------------------------------------------------
+static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" int sisr_bn_finalize(const float* stat_part, const float* cnt_part, int32_t n_tiles, int32_t C,
+                                const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, float momentum, float eps, float* scale, float* shift,
+                                float* save_mean, float* save_invstd, void* stream) {
+    if (!stat_part || !cnt_part || n_tiles <= 0 || C <= 0 || !gamma || !beta || !running_mean || !running_var ||
+        !scale || !shift || !save_mean || !save_invstd)
+        return SISR_E_BADARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(SISR_BLOCK), 0, S_(stream), stat_part,
+                       cnt_part, n_tiles, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
+                       save_mean, save_invstd);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_bn_eval_consts(const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, int32_t C, float* scale, float* shift,
+                                   void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0) return SISR_E_BADARG;
+    hipLaunchKernelGGL(bn_eval_consts_kernel, dim3((C + 255) / 256), dim3(256), 0, S_(stream), gamma, beta,
+                       running_mean, running_var, eps, C, scale, shift);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_bn_bwd_plan(SisrBnBwdDesc* d) {
+    if (!d || d->C < 4 || (d->C & 3) || d->P <= 0) return SISR_E_BADARG;
+    const int G = d->C >> 2;
+    if (G > SISR_BLOCK || (SISR_BLOCK % G) != 0) return SISR_E_UNSUPPORTED;
+    const int PL = SISR_BLOCK / G;
+    const int64_t want = (d->P + (int64_t)PL * 8 - 1) / ((int64_t)PL * 8);   // >= 8 pixels per thread
+    d->grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 1024));
+    return 0;
+}
+
+extern "C" int sisr_bn_bwd(const SisrBnBwdDesc* d, void* stream) {
+    if (!d || !d->dy || !d->x || !d->scale || !d->shift || !d->mean || !d->invstd || !d->gamma || !d->work ||
+        !d->qa || !d->qb || !d->qd || !d->dgamma || !d->dbeta || d->grid <= 0)
+        return SISR_E_BADARG;
+    const int G = d->C >> 2, PL = SISR_BLOCK / G;
+    const int lds = PL * 2 * d->C * 4;
+    if (lds > 64 * 1024) return SISR_E_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(d->grid), dim3(SISR_BLOCK), lds, S_(stream), *d);
+    SISR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(SISR_BLOCK), 0, S_(stream), *d);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_eltwise_res_affine(const float* x1, const float* slope1_p, float slope1, const float* x2,
+                                       const float* pa, const float* pd, float* y, int64_t P, int32_t C,
+                                       void* stream) {
+    if (!x1 || !y || P <= 0 || C <= 0 || (C & 3) || (pa && !pd) || (pa && !x2)) return SISR_E_BADARG;
+    const int64_t n4 = P * C / 4;
+    const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(eltwise_res_affine_kernel, dim3(blocks), dim3(256), 0, S_(stream), x1, slope1_p, slope1, x2, pa,
+                       pd, y, n4, C);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_prelu_slope_grad(const float* dy, const float* pre, int64_t n, float* work, float* out,
+                                     void* stream) {
+    if (!dy || !pre || !work || !out || n <= 0) return SISR_E_BADARG;
+    const int blocks = (int)std::min<int64_t>((n + 2047) / 2048, 1024);
+    hipLaunchKernelGGL(prelu_slope_partial_kernel, dim3(blocks), dim3(SISR_BLOCK), 0, S_(stream), dy, pre, n, work);
+    SISR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(SISR_BLOCK), 0, S_(stream), work, blocks, out);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
+    if (!a || !b || !y || n <= 0) return SISR_E_BADARG;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(add_kernel, dim3(blocks), dim3(256), 0, S_(stream), a, b, y, n);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,188 @@
+// spectral.hip -- weight-side kernels: spectral-norm power iteration, weight packing for the
+// direct-conv kernels, and the weight-gradient epilogue (un-packing + spectral-norm quotient rule).
+//
+// Restates torch.nn.utils.spectral_norm's hook (SpectralNorm.compute_weight), which the reference
+// applies to every trunk convolution of G and every convolution of D (model_generator.py:3,10,13,
+// 33,39,45,52,123; model_discriminator.py:2,10,39):
+//   training: v <- normalize(W_mat^T u), u <- normalize(W_mat v)  (one iteration, eps 1e-12, in place)
+//   sigma = u . (W_mat v);  W = W_orig / sigma;  autograd treats u, v as constants.
+// "Multi-tensor": one launch serves every convolution of a network (descriptor table in HBM).
+#include "sisr_dev.h"
+
+#include <algorithm>
+
+#define SN_EPS 1e-12f
+
+// phase 1: one workgroup per weight -> sigma (+ in-place u/v update, + copies for backward)
+__global__ void __launch_bounds__(SISR_BLOCK) weights_sigma_kernel(const SisrWeightDesc* table) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    __shared__ float scratch[8];
+    const SisrWeightDesc w = table[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows = w.Cout, cols = w.Cin * w.KH * w.KW;
+    if (w.u == nullptr) {
+        if (tid == 0 && w.sigma) w.sigma[0] = 1.f;
+        return;
+    }
+    float* us = sh;            // [rows]
+    float* vs = sh + rows;     // [cols]
+    float* ss = vs + cols;     // [rows]
+    for (int i = tid; i < rows; i += SISR_BLOCK) us[i] = w.u[i];
+    for (int j = tid; j < cols; j += SISR_BLOCK) vs[j] = w.v[j];
+    __syncthreads();
+    if (w.training) {
+        // t = W^T u (thread per column: coalesced along the row-major weight matrix)
+        float part = 0.f;
+        for (int j = tid; j < cols; j += SISR_BLOCK) {
+            float a = 0.f;
+            for (int i = 0; i < rows; ++i) a += w.w_orig[(int64_t)i * cols + j] * us[i];
+            vs[j] = a;
+            part += a * a;
+        }
+        const float nv = sqrtf(block_sum(part, scratch));
+        const float iv = 1.f / fmaxf(nv, SN_EPS);
+        for (int j = tid; j < cols; j += SISR_BLOCK) vs[j] *= iv;
+        __syncthreads();
+    }
+    // s = W v (wave per row)
+    for (int i = wave; i < rows; i += SISR_BLOCK / 64) {
+        float a = 0.f;
+        for (int j = lane; j < cols; j += 64) a += w.w_orig[(int64_t)i * cols + j] * vs[j];
+        a = wave_sum(a);
+        if (lane == 0) ss[i] = a;
+    }
+    __syncthreads();
+    if (w.training) {
+        float part = 0.f;
+        for (int i = tid; i < rows; i += SISR_BLOCK) part += ss[i] * ss[i];
+        const float nu = sqrtf(block_sum(part, scratch));
+        const float iu = 1.f / fmaxf(nu, SN_EPS);
+        for (int i = tid; i < rows; i += SISR_BLOCK) us[i] = ss[i] * iu;
+        __syncthreads();
+    }
+    float part = 0.f;
+    for (int i = tid; i < rows; i += SISR_BLOCK) part += us[i] * ss[i];
+    const float sigma = block_sum(part, scratch);
+    if (tid == 0 && w.sigma) w.sigma[0] = sigma;
+    if (w.training) {
+        for (int i = tid; i < rows; i += SISR_BLOCK) w.u[i] = us[i];
+        for (int j = tid; j < cols; j += SISR_BLOCK) w.v[j] = vs[j];
+    }
+    if (w.u_used) for (int i = tid; i < rows; i += SISR_BLOCK) w.u_used[i] = us[i];
+    if (w.v_used) for (int j = tid; j < cols; j += SISR_BLOCK) w.v_used[j] = vs[j];
+}
+
+// packed channel index -> original output channel (PixelShuffle(2) consumers use (i,j)-major order)
+__device__ __forceinline__ int unpermute_cout(int cp, int Cout, int shuffle2) {
+    if (!shuffle2) return cp;
+    const int Cq = Cout >> 2;
+    const int ij = cp / Cq, c = cp - ij * Cq;
+    return c * 4 + ij;
+}
+
+// phase 2: pack W/sigma.  grid (n_weights, parts); grid-stride over the packed elements.
+__global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeightDesc* table) {
+    const SisrWeightDesc w = table[blockIdx.x];
+    const float inv = 1.f / (w.sigma ? w.sigma[0] : 1.f);
+    const int64_t stride = (int64_t)gridDim.y * SISR_BLOCK;
+    const int64_t start = (int64_t)blockIdx.y * SISR_BLOCK + threadIdx.x;
+    if (w.wpk_fwd) {
+        // [chunk][r][cp][krow], krow = s*PS + (ci - chunk*CK)
+        const int64_t total = (int64_t)w.f_n_chunk * w.KH * w.f_CoutPad * w.f_KROWP;
+        for (int64_t e = start; e < total; e += stride) {
+            int64_t tq = e;
+            const int krow = (int)(tq % w.f_KROWP); tq /= w.f_KROWP;
+            const int cp = (int)(tq % w.f_CoutPad); tq /= w.f_CoutPad;
+            const int r = (int)(tq % w.KH);
+            const int chunk = (int)(tq / w.KH);
+            const int s = krow / w.f_PS, cl = krow - s * w.f_PS;
+            const int ci = chunk * w.f_CK + cl;
+            float val = 0.f;
+            if (s < w.KW && cl < w.f_CK && ci < w.Cin && cp < w.Cout) {
+                const int co = unpermute_cout(cp, w.Cout, w.shuffle2);
+                val = w.w_orig[(((int64_t)co * w.Cin + ci) * w.KH + r) * w.KW + s] * inv;
+            }
+            w.wpk_fwd[e] = val;
+        }
+    }
+    if (w.wpk_dgrad) {
+        // data gradient = conv over dy (channels = couts in packed order) with flipped taps:
+        // Wd[op = ci][ip = cp][r'][s'] = W[co(cp)][ci][KH-1-r'][KW-1-s']
+        const int64_t total = (int64_t)w.d_n_chunk * w.KH * w.d_CoutPad * w.d_KROWP;
+        for (int64_t e = start; e < total; e += stride) {
+            int64_t tq = e;
+            const int krow = (int)(tq % w.d_KROWP); tq /= w.d_KROWP;
+            const int op = (int)(tq % w.d_CoutPad); tq /= w.d_CoutPad;
+            const int r = (int)(tq % w.KH);
+            const int chunk = (int)(tq / w.KH);
+            const int s = krow / w.d_PS, il = krow - s * w.d_PS;
+            const int ip = chunk * w.d_CK + il;
+            float val = 0.f;
+            if (s < w.KW && il < w.d_CK && ip < w.Cout && op < w.Cin) {
+                const int co = unpermute_cout(ip, w.Cout, w.shuffle2);
+                val = w.w_orig[(((int64_t)co * w.Cin + op) * w.KH + (w.KH - 1 - r)) * w.KW + (w.KW - 1 - s)] * inv;
+            }
+            w.wpk_dgrad[e] = val;
+        }
+    }
+}
+
+// weight-gradient epilogue: one workgroup per weight
+__global__ void __launch_bounds__(SISR_BLOCK) weights_grad_kernel(const SisrWeightGradDesc* table) {
+    __shared__ float scratch[8];
+    const SisrWeightGradDesc w = table[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int cols = w.Cin * w.KH * w.KW;
+    const int64_t total = (int64_t)w.Cout * cols;
+    const int Cq = w.Cout >> 2;
+    auto packed_index = [&](int64_t e) -> int64_t {
+        int64_t tq = e;
+        const int s = (int)(tq % w.KW); tq /= w.KW;
+        const int r = (int)(tq % w.KH); tq /= w.KH;
+        const int ci = (int)(tq % w.Cin);
+        const int co = (int)(tq / w.Cin);
+        const int cp = w.shuffle2 ? ((co & 3) * Cq + (co >> 2)) : co;
+        const int chunk = ci / w.CK, cl = ci - chunk * w.CK;
+        const int krow = s * w.PS + cl;
+        return ((int64_t)(chunk * w.KH + r) * w.KROWP + krow) * w.CoutPad + cp;
+    };
+    if (w.grad_bias != nullptr && w.dbias_pk != nullptr) {
+        for (int co = tid; co < w.Cout; co += SISR_BLOCK)
+            w.grad_bias[co] = w.dbias_pk[w.shuffle2 ? ((co & 3) * Cq + (co >> 2)) : co];
+    }
+    if (w.grad == nullptr) return;
+    if (w.u_used == nullptr) {
+        for (int64_t e = tid; e < total; e += SISR_BLOCK) w.grad[e] = w.dwpk[packed_index(e)];
+        return;
+    }
+    const float sigma = w.sigma[0];
+    float part = 0.f;
+    for (int64_t e = tid; e < total; e += SISR_BLOCK) part += w.dwpk[packed_index(e)] * w.w_orig[e];
+    // <G, W> with W = W_orig / sigma
+    const float gw = block_sum(part, scratch) / sigma;
+    const float inv = 1.f / sigma;
+    for (int64_t e = tid; e < total; e += SISR_BLOCK) {
+        const int co = (int)(e / cols), col = (int)(e - (int64_t)co * cols);
+        w.grad[e] = (w.dwpk[packed_index(e)] - gw * w.u_used[co] * w.v_used[col]) * inv;
+    }
+}
+
+extern "C" int sisr_weights_prepare(const SisrWeightDesc* table_dev, int32_t n, void* stream) {
+    if (!table_dev || n <= 0) return SISR_E_BADARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // LDS for the largest supported matrix: rows <= 1024, cols <= 9216
+    const int lds = (2 * 1024 + 9216) * 4;
+    hipLaunchKernelGGL(weights_sigma_kernel, dim3(n), dim3(SISR_BLOCK), lds, st, table_dev);
+    SISR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(weights_pack_kernel, dim3(n, 16), dim3(SISR_BLOCK), 0, st, table_dev);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_weights_grad(const SisrWeightGradDesc* table_dev, int32_t n, void* stream) {
+    if (!table_dev || n <= 0) return SISR_E_BADARG;
+    hipLaunchKernelGGL(weights_grad_kernel, dim3(n), dim3(SISR_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
+                       table_dev);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}

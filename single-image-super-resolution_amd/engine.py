@@ -1,0 +1,380 @@
+"""Host-side engine: turns the reference's layers into launches of the gfx950 kernels.
+
+PyTorch is plumbing here (device memory through the caching allocator, the current HIP stream,
+autograd bookkeeping); every FLOP of the path runs in libsisr_hip.so.  An activation is carried
+as a *lazy operand*: a raw NHWC tensor plus the per-channel affine (BatchNorm apply) and the
+leaky-relu slope (PReLU / LeakyReLU / ReLU) that its consumer applies while staging tiles into
+LDS, so BatchNorm / activation layers never make their own pass over HBM.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _copy_struct(s):
+    return type(s).from_buffer_copy(s)
+
+
+def _align4(n):
+    return (n + 3) & ~3
+
+
+class Operand:
+    """x1 (and x2) + prologue: see SISR_PRO_* in include/sisr_hip.h.  dims = logical (N,H,W,C)."""
+    __slots__ = ('x1', 'x2', 'pa', 'pb', 'pd', 'ps', 'pt', 'mode', 'pro', 'slope', 'dims')
+
+    def __init__(self, x1, dims, pro=L.PRO_NONE, mode=L.X_NHWC, x2=None, pa=None, pb=None, pd=None,
+                 ps=None, pt=None, slope=None):
+        self.x1, self.x2, self.pa, self.pb, self.pd, self.ps, self.pt = x1, x2, pa, pb, pd, ps, pt
+        self.mode, self.pro, self.slope, self.dims = mode, pro, slope, dims
+
+    @staticmethod
+    def plain(t, dims=None, mode=L.X_NHWC):
+        return Operand(t, dims or tuple(t.shape), mode=mode)
+
+    @staticmethod
+    def act(t, slope, dims=None):
+        """lrelu(t, slope); slope: device scalar tensor (PReLU weight) or float."""
+        return Operand(t, dims or tuple(t.shape), pro=L.PRO_ACT, slope=slope)
+
+    @staticmethod
+    def affine_act(t, scale, shift, slope=1.0):
+        return Operand(t, tuple(t.shape), pro=L.PRO_AFFINE_ACT, pa=scale, pd=shift, slope=slope)
+
+    def fill(self, d, g=False):
+        """write this operand into a ConvDesc / WgradDesc (g=True: the output-gradient operand)"""
+        names = (('g1', 'g2', 'qa', 'qb', 'qd', 'qs', 'qt', 'g_mode', 'gpro_mode', 'gpro_slope_p', 'gpro_slope')
+                 if g else
+                 ('x1', 'x2', 'pa', 'pb', 'pd', 'ps', 'pt', 'x_mode', 'pro_mode', 'pro_slope_p', 'pro_slope'))
+        vals = (self.x1, self.x2, self.pa, self.pb, self.pd, self.ps, self.pt)
+        for n, v in zip(names[:7], vals):
+            setattr(d, n, _ptr(v))
+        setattr(d, names[7], self.mode)
+        setattr(d, names[8], self.pro)
+        if isinstance(self.slope, torch.Tensor):
+            setattr(d, names[9], self.slope.data_ptr())
+            setattr(d, names[10], 1.0)
+        else:
+            setattr(d, names[9], None)
+            setattr(d, names[10], 1.0 if self.slope is None else float(self.slope))
+
+
+class ConvGeom:
+    """Static geometry of one convolution + cached kernel plans per input shape."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=None, shuffle2=False):
+        self.cin, self.cout, self.k, self.stride = cin, cout, k, stride
+        self.pad = (k // 2) if pad is None else pad
+        self.shuffle2 = shuffle2
+        self._plans = {}
+
+    def out_hw(self, h, w):
+        return ((h + 2 * self.pad - self.k) // self.stride + 1, (w + 2 * self.pad - self.k) // self.stride + 1)
+
+    def plans(self, n, h, w, max_pixel_blocks=512):
+        key = (n, h, w)
+        if key in self._plans:
+            return self._plans[key]
+        lib = L.lib()
+        ho, wo = self.out_hw(h, w)
+        f = L.ConvDesc()
+        f.N, f.H, f.W, f.Cin, f.Ho, f.Wo, f.Cout = n, h, w, self.cin, ho, wo, self.cout
+        f.KH = f.KW = self.k
+        f.stride, f.pad_y, f.pad_x = self.stride, self.pad, self.pad
+        f.y_sy = f.y_sx = 1
+        f.y_oy = f.y_ox = 0
+        f.y_H, f.y_W = ho, wo
+        f.y_mode = L.Y_SHUFFLE2 if self.shuffle2 else L.Y_NHWC
+        L.check(lib.sisr_conv2d_plan(C.byref(f)), 'sisr_conv2d_plan(fwd)')
+        d = None
+        if self.stride == 1:
+            d = L.ConvDesc()      # data gradient: conv over dy with flipped taps, roles swapped
+            d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, ho, wo, self.cout, h, w, self.cin
+            d.KH = d.KW = self.k
+            d.stride = 1
+            d.pad_y = d.pad_x = self.k - 1 - self.pad
+            d.y_sy = d.y_sx = 1
+            d.y_H, d.y_W = h, w
+            L.check(lib.sisr_conv2d_plan(C.byref(d)), 'sisr_conv2d_plan(dgrad)')
+        g = L.WgradDesc()
+        g.N, g.H, g.W, g.Cin, g.Ho, g.Wo, g.Cout = n, h, w, self.cin, ho, wo, self.cout
+        g.KH = g.KW = self.k
+        g.stride, g.pad_y, g.pad_x = self.stride, self.pad, self.pad
+        L.check(lib.sisr_wgrad_plan(C.byref(g), max_pixel_blocks), 'sisr_wgrad_plan')
+        g.slab_stride = g.slab_elems + g.CoutPad
+        self._plans[key] = (f, d, g)
+        return self._plans[key]
+
+
+class ConvRef:
+    """One convolution of a network: geometry + where its parameters / spectral-norm buffers live."""
+
+    def __init__(self, geom, weight, bias, u=None, v=None):
+        self.geom, self.weight, self.bias, self.u, self.v = geom, weight, bias, u, v
+
+
+class Prepared:
+    """Per-forward products of sisr_weights_prepare for one conv (kept for the backward pass)."""
+    __slots__ = ('ref', 'plans', 'wpk_fwd', 'wpk_dgrad', 'sigma', 'u_used', 'v_used')
+
+
+def prepare_weights(items, training, need_dgrad=True):
+    """items: [(ConvRef, n, h, w)].  One multi-tensor launch: spectral-norm power iteration (in
+    place on u/v when training), sigma, and the packed W/sigma images for fwd and dgrad."""
+    lib = L.lib()
+    dev = items[0][0].weight.device
+    total, small = 0, 0
+    metas = []
+    for ref, n, h, w in items:
+        f, d, g = ref.geom.plans(n, h, w)
+        off_f = total
+        total += _align4(f.plan.wpk_elems)
+        off_d = None
+        if need_dgrad and d is not None:
+            off_d = total
+            total += _align4(d.plan.wpk_elems)
+        off_s = small
+        small += 4 + (_align4(ref.geom.cout) + _align4(ref.geom.cin * ref.geom.k * ref.geom.k) if ref.u is not None else 0)
+        metas.append((off_f, off_d, off_s))
+    big = torch.empty(total, dtype=torch.float32, device=dev)
+    sm = torch.empty(small, dtype=torch.float32, device=dev)
+    table = (L.WeightDesc * len(items))()
+    out = []
+    for i, ((ref, n, h, w), (off_f, off_d, off_s)) in enumerate(zip(items, metas)):
+        f, d, g = ref.geom.plans(n, h, w)
+        gm = ref.geom
+        p = Prepared()
+        p.ref, p.plans = ref, (f, d, g)
+        p.wpk_fwd = big[off_f:off_f + f.plan.wpk_elems]
+        p.wpk_dgrad = big[off_d:off_d + d.plan.wpk_elems] if off_d is not None else None
+        p.sigma = sm[off_s:off_s + 1]
+        t = table[i]
+        t.w_orig = ref.weight.data_ptr()
+        t.sigma = p.sigma.data_ptr()
+        t.wpk_fwd = p.wpk_fwd.data_ptr()
+        t.wpk_dgrad = _ptr(p.wpk_dgrad)
+        t.Cout, t.Cin, t.KH, t.KW = gm.cout, gm.cin, gm.k, gm.k
+        t.training, t.shuffle2 = int(training), int(gm.shuffle2)
+        t.f_CK, t.f_PS, t.f_KROWP, t.f_n_chunk, t.f_CoutPad = (f.plan.CK, f.plan.PS, f.plan.KROWP,
+                                                                 f.plan.n_chunk, f.plan.CoutPad)
+        if off_d is not None:
+            t.d_CK, t.d_PS, t.d_KROWP, t.d_n_chunk, t.d_CoutPad = (d.plan.CK, d.plan.PS, d.plan.KROWP,
+                                                                     d.plan.n_chunk, d.plan.CoutPad)
+        p.u_used = p.v_used = None
+        if ref.u is not None:
+            rows, cols = gm.cout, gm.cin * gm.k * gm.k
+            if rows > 1024 or cols > 9216:
+                raise RuntimeError('spectral-norm matrix %dx%d exceeds the kernel limit' % (rows, cols))
+            p.u_used = sm[off_s + 4:off_s + 4 + rows]
+            p.v_used = sm[off_s + 4 + _align4(rows):off_s + 4 + _align4(rows) + cols]
+            t.u, t.v = ref.u.data_ptr(), ref.v.data_ptr()
+            t.u_used, t.v_used = p.u_used.data_ptr(), p.v_used.data_ptr()
+        out.append(p)
+    tab_dev = _table_to_device(table, dev)
+    L.check(lib.sisr_weights_prepare(tab_dev.data_ptr(), len(items), _stream()), 'sisr_weights_prepare')
+    return out, (big, sm, tab_dev)
+
+
+def _table_to_device(table, dev):
+    host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
+    return host.to(dev, non_blocking=False)
+
+
+def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, res=None, out=None):
+    """Launch the forward conv of `prep` on lazy operand `op`.  Returns (y, stat_part, cnt_part)."""
+    lib = L.lib()
+    f = _copy_struct(prep.plans[0])
+    gm = prep.ref.geom
+    n, h, w, c = op.dims
+    assert (n, h, w, c) == (f.N, f.H, f.W, f.Cin), ((n, h, w, c), (f.N, f.H, f.W, f.Cin))
+    if y_mode is not None:
+        f.y_mode = y_mode
+    dev = op.x1.device
+    if out is None:
+        if f.y_mode == L.Y_NCHW:
+            out = torch.empty((n, gm.cout, f.Ho, f.Wo), dtype=torch.float32, device=dev)
+        elif f.y_mode == L.Y_SHUFFLE2:
+            out = torch.empty((n, 2 * f.Ho, 2 * f.Wo, gm.cout // 4), dtype=torch.float32, device=dev)
+        else:
+            out = torch.empty((n, f.Ho, f.Wo, gm.cout), dtype=torch.float32, device=dev)
+    op.fill(f)
+    f.wpk, f.bias, f.res, f.y = prep.wpk_fwd.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr()
+    f.epi_act = epi
+    sp = cp = None
+    if stats:
+        sp = torch.empty((f.plan.n_tiles, 2, gm.cout), dtype=torch.float32, device=dev)
+        cp = torch.empty((f.plan.n_tiles,), dtype=torch.float32, device=dev)
+        f.stat_part, f.cnt_part = sp.data_ptr(), cp.data_ptr()
+    L.check(lib.sisr_conv2d_f32(C.byref(f), _stream()), 'sisr_conv2d_f32(fwd)')
+    return out, sp, cp
+
+
+def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC):
+    """Data gradient: conv over the (lazy) output gradient with the flipped packed weights."""
+    lib = L.lib()
+    d = _copy_struct(prep.plans[1])
+    gm = prep.ref.geom
+    assert tuple(dy_op.dims) == (d.N, d.H, d.W, d.Cin), (dy_op.dims, (d.N, d.H, d.W, d.Cin))
+    dev = dy_op.x1.device
+    d.y_mode = y_mode
+    if y_mode == L.Y_NCHW:
+        out = torch.empty((d.N, gm.cin, d.Ho, d.Wo), dtype=torch.float32, device=dev)
+    else:
+        out = torch.empty((d.N, d.Ho, d.Wo, gm.cin), dtype=torch.float32, device=dev)
+    dy_op.fill(d)
+    d.wpk, d.bias, d.res, d.y = prep.wpk_dgrad.data_ptr(), None, _ptr(res), out.data_ptr()
+    L.check(lib.sisr_conv2d_f32(C.byref(d), _stream()), 'sisr_conv2d_f32(dgrad)')
+    return out
+
+
+def conv_wgrad(prep, x_op, dy_op):
+    """Weight + bias gradient in packed layout: returns the reduced [slab_elems + CoutPad] buffer."""
+    lib = L.lib()
+    g = _copy_struct(prep.plans[2])
+    assert tuple(x_op.dims) == (g.N, g.H, g.W, g.Cin) and tuple(dy_op.dims) == (g.N, g.Ho, g.Wo, g.Cout), \
+        (x_op.dims, dy_op.dims)
+    dev = x_op.x1.device
+    stride = g.slab_stride
+    slab = torch.empty((g.n_slabs, stride), dtype=torch.float32, device=dev)
+    x_op.fill(g)
+    dy_op.fill(g, g=True)
+    g.slab = slab.data_ptr()
+    g.bias_slab = slab.data_ptr() + 4 * g.slab_elems
+    L.check(lib.sisr_conv2d_wgrad_f32(C.byref(g), _stream()), 'sisr_conv2d_wgrad_f32')
+    red = torch.empty((stride,), dtype=torch.float32, device=dev)
+    L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), red.data_ptr(), g.n_slabs, stride, _stream()),
+            'sisr_slab_reduce_f32')
+    return red
+
+
+class WeightGradBatch:
+    """Collects (prepared conv, reduced packed gradient) pairs; one launch un-packs them all."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, prep, red, want_w=True, want_b=True):
+        self.items.append((prep, red, want_w, want_b))
+
+    def run(self):
+        """returns {id(ConvRef): (grad_w or None, grad_b or None)}"""
+        if not self.items:
+            return {}
+        lib = L.lib()
+        table = (L.WeightGradDesc * len(self.items))()
+        res = {}
+        dev = self.items[0][1].device
+        for i, (p, red, want_w, want_b) in enumerate(self.items):
+            g = p.plans[2]
+            gm = p.ref.geom
+            t = table[i]
+            gw = torch.empty_like(p.ref.weight) if want_w else None
+            gb = torch.empty_like(p.ref.bias) if (want_b and p.ref.bias is not None) else None
+            t.dwpk, t.w_orig, t.grad = red.data_ptr(), p.ref.weight.data_ptr(), _ptr(gw)
+            t.u_used, t.v_used, t.sigma = _ptr(p.u_used), _ptr(p.v_used), p.sigma.data_ptr()
+            t.dbias_pk = red.data_ptr() + 4 * g.slab_elems
+            t.grad_bias = _ptr(gb)
+            t.Cout, t.Cin, t.KH, t.KW, t.shuffle2 = gm.cout, gm.cin, gm.k, gm.k, int(gm.shuffle2)
+            t.CK, t.PS, t.KROWP, t.n_chunk, t.CoutPad = g.CK, g.PS, g.KROWP, g.n_chunk, g.CoutPad
+            res[id(p.ref)] = (gw, gb)
+        tab = _table_to_device(table, dev)
+        L.check(lib.sisr_weights_grad(tab.data_ptr(), len(self.items), _stream()), 'sisr_weights_grad')
+        self._keep = tab
+        return res
+
+
+def bn_finalize(sp, cp, bn, eps=1e-5, momentum=0.1):
+    """-> consts [4, C]: scale, shift, batch mean, invstd; updates bn.running_* in place."""
+    lib = L.lib()
+    cch = bn.weight.numel()
+    k = torch.empty((4, cch), dtype=torch.float32, device=sp.device)
+    L.check(lib.sisr_bn_finalize(sp.data_ptr(), cp.data_ptr(), sp.shape[0], cch, bn.weight.data_ptr(),
+                                 bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                 momentum, eps, k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr(),
+                                 k[3].data_ptr(), _stream()), 'sisr_bn_finalize')
+    return k
+
+
+def bn_eval_consts(bn, eps=1e-5):
+    lib = L.lib()
+    cch = bn.weight.numel()
+    k = torch.empty((4, cch), dtype=torch.float32, device=bn.weight.device)
+    L.check(lib.sisr_bn_eval_consts(bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                    bn.running_var.data_ptr(), eps, cch, k[0].data_ptr(), k[1].data_ptr(),
+                                    _stream()), 'sisr_bn_eval_consts')
+    return k
+
+
+def bn_backward(dy, x, consts, gamma, slope=None):
+    """Reductions of BatchNorm backward (+ the leaky activation after it when slope is given).
+    Returns (q [3,C] = qa,qb,qd ; dgamma ; dbeta ; dslope or None)."""
+    lib = L.lib()
+    cch = x.shape[-1]
+    d = L.BnBwdDesc()
+    d.P, d.C = x.numel() // cch, cch
+    d.act_mode = 0 if slope is None else 1
+    if isinstance(slope, torch.Tensor):
+        d.slope_p, d.slope = slope.data_ptr(), 1.0
+    else:
+        d.slope_p, d.slope = None, 1.0 if slope is None else float(slope)
+    L.check(lib.sisr_bn_bwd_plan(C.byref(d)), 'sisr_bn_bwd_plan')
+    dev = x.device
+    work = torch.empty((d.grid, 2 * cch + 1), dtype=torch.float32, device=dev)
+    q = torch.empty((3, cch), dtype=torch.float32, device=dev)
+    dgamma = torch.empty((cch,), dtype=torch.float32, device=dev)
+    dbeta = torch.empty((cch,), dtype=torch.float32, device=dev)
+    dslope = torch.empty((1,), dtype=torch.float32, device=dev) if slope is not None else None
+    d.dy, d.x = dy.data_ptr(), x.data_ptr()
+    d.scale, d.shift, d.mean, d.invstd = (consts[0].data_ptr(), consts[1].data_ptr(), consts[2].data_ptr(),
+                                          consts[3].data_ptr())
+    d.gamma, d.work = gamma.data_ptr(), work.data_ptr()
+    d.qa, d.qb, d.qd = q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr()
+    d.dgamma, d.dbeta, d.dslope = dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dslope)
+    L.check(lib.sisr_bn_bwd(C.byref(d), _stream()), 'sisr_bn_bwd')
+    return q, dgamma, dbeta, dslope
+
+
+def eltwise_res_affine(x1, slope1, x2=None, pa=None, pd=None):
+    """y = lrelu(x1, slope1) + (pa*x2 + pd | x2 | 0) over NHWC tensors."""
+    lib = L.lib()
+    y = torch.empty_like(x1)
+    cch = x1.shape[-1]
+    sp, sv = (slope1.data_ptr(), 1.0) if isinstance(slope1, torch.Tensor) else \
+        (None, 1.0 if slope1 is None else float(slope1))
+    L.check(lib.sisr_eltwise_res_affine(x1.data_ptr(), sp, sv, _ptr(x2), _ptr(pa), _ptr(pd), y.data_ptr(),
+                                        x1.numel() // cch, cch, _stream()), 'sisr_eltwise_res_affine')
+    return y
+
+
+def prelu_slope_grad(dy, pre):
+    lib = L.lib()
+    work = torch.empty((1024,), dtype=torch.float32, device=dy.device)
+    out = torch.empty((1,), dtype=torch.float32, device=dy.device)
+    L.check(lib.sisr_prelu_slope_grad(dy.data_ptr(), pre.data_ptr(), dy.numel(), work.data_ptr(),
+                                      out.data_ptr(), _stream()), 'sisr_prelu_slope_grad')
+    return out
+
+
+def add(a, b):
+    lib = L.lib()
+    y = torch.empty_like(a)
+    L.check(lib.sisr_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), 'sisr_add')
+    return y
+
+
+def require_gpu_tensor(x, what):
+    if not (isinstance(x, torch.Tensor) and x.is_cuda):
+        raise RuntimeError('%s: this path runs only on an MI355X device tensor (got %s); there is no '
+                           'CPU fallback' % (what, getattr(x, 'device', type(x))))
+    if x.dtype != torch.float32:
+        raise RuntimeError('%s: fp32 tensors expected, got %s' % (what, x.dtype))

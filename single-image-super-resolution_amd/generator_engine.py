@@ -1,0 +1,213 @@
+"""Hand-scheduled forward / backward of the generator family on the gfx950 kernels.
+
+One topology covers SURVEY rows a2-a4: ``Generator`` (model_generator.py:22-101), any stack of
+``GeneratorSuffix`` wrappers (model_generator.py:117-141) and the progressive generator
+(model_generator_progressive.py:21-65):
+
+    9x9 conv -> PReLU -> n x [conv-BN-PReLU-conv-BN + skip] -> conv-BN (+ long skip) ->
+    k x [conv -> PixelShuffle(2) -> PReLU] -> conv -> tanh
+
+Schedule (what crosses HBM): every conv writes its raw output once; BatchNorm-apply and PReLU are
+folded into the NEXT conv's tile staging; BatchNorm batch statistics come out of the producing
+conv's epilogue; only the block skip-sum is materialised by an elementwise pass.  The backward
+mirrors it: BatchNorm/PReLU backward are prologues of the data- and weight-gradient convs; the
+only extra passes are the two per-BatchNorm reductions.
+"""
+import torch
+
+from . import _lib as L
+from . import engine as E
+from .engine import Operand
+
+
+class Topology:
+    """Where the parameters of the generator family live (filled by the nn.Module wrappers)."""
+
+    def __init__(self):
+        self.first = None          # ConvRef (9x9)
+        self.first_prelu = None    # Parameter [1]
+        self.blocks = []           # dicts: c1, bn1, prelu, c2, bn2
+        self.trunk_end = None      # ConvRef
+        self.trunk_bn = None
+        self.long_skip = True
+        self.stages = []           # (ConvRef with shuffle2 geometry, prelu Parameter)
+        self.end = None            # ConvRef -> tanh
+
+    def conv_refs(self):
+        refs = [self.first]
+        for b in self.blocks:
+            refs += [b['c1'], b['c2']]
+        refs.append(self.trunk_end)
+        refs += [s[0] for s in self.stages]
+        refs.append(self.end)
+        return refs
+
+    def bn_modules(self):
+        mods = []
+        for b in self.blocks:
+            mods += [b['bn1'], b['bn2']]
+        mods.append(self.trunk_bn)
+        return mods
+
+
+class Saved:
+    pass
+
+
+def run_forward(topo, x, training):
+    """x: NCHW fp32 device tensor.  Returns (out NCHW, Saved)."""
+    E.require_gpu_tensor(x, 'generator input')
+    x = x.contiguous()
+    n, cimg, h, w = x.shape
+    refs = topo.conv_refs()
+    items = [(topo.first, n, h, w)]
+    for b in topo.blocks:
+        items += [(b['c1'], n, h, w), (b['c2'], n, h, w)]
+    items.append((topo.trunk_end, n, h, w))
+    hh, ww = h, w
+    for ref, _ in topo.stages:
+        items.append((ref, n, hh, ww))
+        hh, ww = hh * 2, ww * 2
+    items.append((topo.end, n, hh, ww))
+    preps, keep = E.prepare_weights(items, training)
+    P = {id(r): p for r, p in zip(refs, preps)}
+    sv = Saved()
+    sv.topo, sv.P, sv.keep, sv.x, sv.training = topo, P, keep, x, training
+    sv.blocks = []
+
+    def bn_consts(conv_out, bn):
+        y, sp, cp = conv_out
+        return E.bn_finalize(sp, cp, bn) if training else E.bn_eval_consts(bn)
+
+    # first conv (+ lazily applied PReLU)
+    x_op = Operand.plain(x, dims=(n, h, w, cimg), mode=L.X_NCHW)
+    t0_pre, _, _ = E.conv_forward(P[id(topo.first)], x_op, bias=topo.first.bias)
+    sv.t0_pre = t0_pre
+    cur_raw, cur_slope = t0_pre, topo.first_prelu       # current activation = lrelu(cur_raw, cur_slope)
+    for b in topo.blocks:
+        rec = Saved()
+        rec.in_raw, rec.in_slope = cur_raw, cur_slope
+        in_op = Operand.act(cur_raw, cur_slope) if cur_slope is not None else Operand.plain(cur_raw)
+        o1 = E.conv_forward(P[id(b['c1'])], in_op, bias=b['c1'].bias, stats=training)
+        rec.c1, rec.k1 = o1[0], bn_consts(o1, b['bn1'])
+        o2 = E.conv_forward(P[id(b['c2'])], Operand.affine_act(rec.c1, rec.k1[0], rec.k1[1], b['prelu']),
+                            bias=b['c2'].bias, stats=training)
+        rec.c2, rec.k2 = o2[0], bn_consts(o2, b['bn2'])
+        cur_raw = E.eltwise_res_affine(cur_raw, cur_slope, rec.c2, rec.k2[0], rec.k2[1])
+        cur_slope = None
+        sv.blocks.append(rec)
+    sv.xl_raw, sv.xl_slope = cur_raw, cur_slope
+    in_op = Operand.act(cur_raw, cur_slope) if cur_slope is not None else Operand.plain(cur_raw)
+    oe = E.conv_forward(P[id(topo.trunk_end)], in_op, bias=topo.trunk_end.bias, stats=training)
+    sv.ce, sv.ke = oe[0], bn_consts(oe, topo.trunk_bn)
+    if topo.long_skip:
+        sv.t = E.eltwise_res_affine(t0_pre, topo.first_prelu, sv.ce, sv.ke[0], sv.ke[1])
+        cur = Operand.plain(sv.t)
+    else:
+        cur = Operand.affine_act(sv.ce, sv.ke[0], sv.ke[1], 1.0)
+    sv.stage_in, sv.stage_pre = [], []
+    for ref, slope in topo.stages:
+        sv.stage_in.append(cur)
+        pre, _, _ = E.conv_forward(P[id(ref)], cur, bias=ref.bias)       # PixelShuffle on store
+        sv.stage_pre.append(pre)
+        cur = Operand.act(pre, slope)
+    sv.end_in = cur
+    out, _, _ = E.conv_forward(P[id(topo.end)], cur, bias=topo.end.bias, y_mode=L.Y_NCHW, epi=L.EPI_TANH)
+    sv.out = out
+    if training:
+        torch._foreach_add_([m.num_batches_tracked for m in topo.bn_modules()], 1)
+    return out, sv
+
+
+def run_backward(sv, grad_out, need_dx):
+    """Returns ({id(param): grad}, grad_x or None)."""
+    if not sv.training:
+        raise NotImplementedError('backward through an eval-mode (running-statistics) generator forward '
+                                  'is not implemented in the HIP path')
+    topo, P = sv.topo, sv.P
+    E.require_gpu_tensor(grad_out, 'generator grad_output')
+    grad_out = grad_out.contiguous()
+    grads = {}
+    wg = E.WeightGradBatch()
+
+    def conv_bwd(ref, x_op, dy_op, need_dgrad=True, res=None, y_mode=L.Y_NHWC):
+        p = P[id(ref)]
+        want_w, want_b = ref.weight.requires_grad, ref.bias is not None and ref.bias.requires_grad
+        if want_w or want_b:
+            wg.add(p, E.conv_wgrad(p, x_op, dy_op), want_w, want_b)
+        return E.conv_dgrad(p, dy_op, res=res, y_mode=y_mode) if need_dgrad else None
+
+    n = sv.x.shape[0]
+    # ---- end conv + tanh ---------------------------------------------------------------------------
+    ho, wo = sv.out.shape[2], sv.out.shape[3]
+    dy = Operand(grad_out, (n, ho, wo, sv.out.shape[1]), pro=L.PRO_TANH_BWD, mode=L.X_NCHW, x2=sv.out)
+    g = conv_bwd(topo.end, sv.end_in, dy)                  # grad wrt the (activated) input of `end`
+    # ---- upscale stages, last to first ---------------------------------------------------------------
+    for k in range(len(topo.stages) - 1, -1, -1):
+        ref, slope = topo.stages[k]
+        pre = sv.stage_pre[k]
+        if slope.requires_grad:
+            grads[id(slope)] = E.prelu_slope_grad(g, pre)
+        hk, wk, cq = pre.shape[1] // 2, pre.shape[2] // 2, pre.shape[3]
+        dy = Operand(g, (n, hk, wk, 4 * cq), pro=L.PRO_ACT_BWD, mode=L.X_UNSHUFFLE2, x2=pre, slope=slope)
+        g = conv_bwd(ref, sv.stage_in[k], dy)
+    # ---- trunk end: conv + BN (+ long skip) ----------------------------------------------------------
+    g_t = g                                               # grad wrt BN_e output (and wrt t0 via the skip)
+    bn = topo.trunk_bn
+    q, dgam, dbet, _ = E.bn_backward(g_t, sv.ce, sv.ke, bn.weight)
+    grads[id(bn.weight)], grads[id(bn.bias)] = dgam, dbet
+    dy = Operand(g_t, tuple(sv.ce.shape), pro=L.PRO_BNBWD, x2=sv.ce, pa=q[0], pb=q[1], pd=q[2])
+    xl_op = Operand.act(sv.xl_raw, sv.xl_slope) if sv.xl_slope is not None else Operand.plain(sv.xl_raw)
+    g = conv_bwd(topo.trunk_end, xl_op, dy)
+    # ---- residual blocks, last to first ----------------------------------------------------------------
+    for b, rec in zip(reversed(topo.blocks), reversed(sv.blocks)):
+        q2, dgam, dbet, _ = E.bn_backward(g, rec.c2, rec.k2, b['bn2'].weight)
+        grads[id(b['bn2'].weight)], grads[id(b['bn2'].bias)] = dgam, dbet
+        dy2 = Operand(g, tuple(rec.c2.shape), pro=L.PRO_BNBWD, x2=rec.c2, pa=q2[0], pb=q2[1], pd=q2[2])
+        a1_op = Operand.affine_act(rec.c1, rec.k1[0], rec.k1[1], b['prelu'])
+        g_a1 = conv_bwd(b['c2'], a1_op, dy2)
+        q1, dgam, dbet, dsl = E.bn_backward(g_a1, rec.c1, rec.k1, b['bn1'].weight, slope=b['prelu'])
+        grads[id(b['bn1'].weight)], grads[id(b['bn1'].bias)] = dgam, dbet
+        grads[id(b['prelu'])] = dsl
+        dy1 = Operand(g_a1, tuple(rec.c1.shape), pro=L.PRO_BNACT_BWD, x2=rec.c1, pa=q1[0], pb=q1[1],
+                      pd=q1[2], ps=rec.k1[0], pt=rec.k1[1], slope=b['prelu'])
+        in_op = Operand.act(rec.in_raw, rec.in_slope) if rec.in_slope is not None else Operand.plain(rec.in_raw)
+        g = conv_bwd(b['c1'], in_op, dy1, res=g)          # + skip gradient, fused in the epilogue
+    # ---- first conv + PReLU -----------------------------------------------------------------------------
+    g_t0 = E.add(g, g_t) if topo.long_skip else g
+    if topo.first_prelu.requires_grad:
+        grads[id(topo.first_prelu)] = E.prelu_slope_grad(g_t0, sv.t0_pre)
+    dy0 = Operand(g_t0, tuple(sv.t0_pre.shape), pro=L.PRO_ACT_BWD, x2=sv.t0_pre, slope=topo.first_prelu)
+    x_op = Operand.plain(sv.x, dims=(n, sv.x.shape[2], sv.x.shape[3], sv.x.shape[1]), mode=L.X_NCHW)
+    gx = conv_bwd(topo.first, x_op, dy0, need_dgrad=need_dx, y_mode=L.Y_NCHW)
+    for ref_id, (gw, gb) in wg.run().items():
+        ref = next(r for r in topo.conv_refs() if id(r) == ref_id)
+        if gw is not None:
+            grads[id(ref.weight)] = gw
+        if gb is not None:
+            grads[id(ref.bias)] = gb
+    return grads, gx
+
+
+class GeneratorFunction(torch.autograd.Function):
+    """autograd node for a whole generator forward: inputs (x, *parameters) -> image."""
+
+    @staticmethod
+    def forward(ctx, topo, training, x, *params):
+        out, sv = run_forward(topo, x, training)
+        ctx.sv, ctx.params = sv, params
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grads, gx = run_backward(ctx.sv, grad_out, ctx.needs_input_grad[2])
+        ctx.sv = None
+        return (None, None, gx) + tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
+
+
+def generator_apply(topo, module, x):
+    params = [p for p in module.parameters()]
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+        return GeneratorFunction.apply(topo, module.training, x, *params)
+    out, _ = run_forward(topo, x, module.training)
+    return out

@@ -1,0 +1,57 @@
+"""GPU: golden parity of the generator family drop-ins (rows a2-a4) against the vectors captured
+from the reference modules, within BASELINE.json's 1e-3 relative fp32 tolerance."""
+import pytest
+import torch
+
+from gpu_helpers import pkg
+from helpers import GEN_CASES, PROG_CASES, grads_close, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def build(cfg):
+    if cfg['kind'] == 'generator':
+        mg = pkg('model_generator')
+        g = mg.Generator(cfg['n_blocks'], cfg['nf'], cfg['nl'], cfg['list_scales'], use_sn=cfg['use_sn'])
+        for _ in range(cfg['n_suffix']):
+            g = mg.GeneratorSuffix(g)
+        return g
+    mp = pkg('model_generator_progressive')
+    g = mp.GeneratorProgresiveBase(cfg['n_blocks'], n_features=cfg['nf'])
+    nf = cfg['nf']
+    for i in range(cfg['n_suffix']):
+        g = mp.GeneratorSuffix(g if i == 0 else g.beginning, n_features=nf)
+        nf //= 4
+    return g
+
+
+@pytest.mark.parametrize('name', GEN_CASES + PROG_CASES)
+def test_generator_matches_reference_golden(name):
+    z, cfg, state, grads, after = load_case(name)
+    net = build(cfg)
+    net.load_state_dict(state, strict=True)
+    net = net.cuda().train()
+    x = torch.from_numpy(z['x']).cuda().requires_grad_(True)
+    r = torch.from_numpy(z['r']).cuda()
+    out = net(x)
+    assert rel_err(out.detach().cpu(), z['out']) < TOL
+    (out * r).sum().backward()
+    assert rel_err(x.grad.cpu(), z['grad_x']) < TOL
+    got = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+    assert set(got) == set(grads)
+    assert grads_close(got, grads, TOL) == []
+    sd = net.state_dict()
+    for k, v in after.items():
+        assert rel_err(sd[k].cpu().double(), v.double()) < TOL, k
+    with torch.no_grad():
+        assert rel_err(net(x).cpu(), z['out2']) < TOL          # advanced SN/BN state
+        net.eval()
+        assert rel_err(net(x).cpu(), z['out_eval']) < TOL      # running statistics, no power iteration
+
+
+def test_no_silent_cpu_path():
+    mg = pkg('model_generator')
+    g = mg.Generator(1, 16, 64, [2])
+    with pytest.raises(RuntimeError):
+        g(torch.zeros(1, 3, 8, 8))          # CPU tensor: must refuse, never fall back

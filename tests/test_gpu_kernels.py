@@ -1,0 +1,221 @@
+"""GPU: kernel-level parity of the C ABI entry points against torch-CPU primitives (the same
+primitives the oracle restates).  Tolerance 1e-4 relative (fp32 MFMA is an exact fmaf chain; only
+summation order differs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_helpers import FakeConv, maxrel, nchw, nhwc, pkg
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+@pytest.fixture(scope='module')
+def E():
+    return pkg('engine')
+
+
+@pytest.fixture(scope='module')
+def L():
+    return pkg('_lib')
+
+
+def test_mfma_lane_layout(L):
+    out = torch.zeros(32 * 32, device='cuda')
+    L.check(L.lib().sisr_mfma_selftest(out.data_ptr(), torch.cuda.current_stream().cuda_stream), 'selftest')
+    i = torch.arange(32, dtype=torch.float64)[:, None]
+    j = torch.arange(32, dtype=torch.float64)[None, :]
+    ref = sum((3 * i + 7 * k + 1) * (5 * k - 2 * j + 11) for k in range(8))
+    assert torch.equal(out.cpu().double().reshape(32, 32), ref)
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+CONV_CASES = [
+    # n, cin, cout, k, stride, h, w
+    (2, 64, 64, 3, 1, 12, 12),
+    (1, 64, 64, 3, 1, 37, 29),
+    (2, 3, 64, 9, 1, 12, 12),
+    (2, 64, 3, 3, 1, 10, 14),
+    (2, 16, 16, 3, 1, 9, 8),
+    (1, 4, 4, 3, 1, 16, 16),
+    (1, 1, 3, 3, 1, 16, 16),
+    (2, 32, 128, 3, 1, 8, 8),
+    (2, 64, 128, 3, 2, 16, 16),
+    (2, 128, 64, 3, 1, 6, 6),
+    (3, 3, 16, 3, 1, 16, 16),
+    (2, 48, 40, 3, 1, 7, 9),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_forward_dgrad_wgrad(E, L, case):
+    n, cin, cout, k, stride, h, w = case
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((cout, cin, k, k), 2, (1.0 / (cin * k * k)) ** 0.5 * 1.7)
+    b = _rand((cout,), 3, 0.1)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, br, stride=stride, padding=k // 2)
+    r = _rand(tuple(y_ref.shape), 4)
+    (y_ref * r).sum().backward()
+
+    geom = E.ConvGeom(cin, cout, k, stride, k // 2)
+    ref = FakeConv(wt.cuda(), b.cuda(), geom)
+    preps, keep = E.prepare_weights([(ref, n, h, w)], training=True, need_dgrad=(stride == 1))
+    p = preps[0]
+    xd = nhwc(x).cuda()
+    y, _, _ = E.conv_forward(p, E.Operand.plain(xd), bias=ref.bias)
+    assert maxrel(nchw(y), y_ref) < TOL, 'forward'
+    rd = nhwc(r).cuda()
+    red = E.conv_wgrad(p, E.Operand.plain(xd), E.Operand.plain(rd))
+    wg = E.WeightGradBatch()
+    wg.add(p, red)
+    gw, gb = wg.run()[id(ref)]
+    assert maxrel(gw, wr.grad) < TOL, 'wgrad'
+    assert maxrel(gb, br.grad) < TOL, 'bias grad'
+    if stride == 1:
+        dx = E.conv_dgrad(p, E.Operand.plain(rd))
+        assert maxrel(nchw(dx), xr.grad) < TOL, 'dgrad'
+
+
+def test_conv_nchw_in_shuffle_out_tanh_and_stats(E, L):
+    n, h, w = 2, 10, 12
+    # NCHW 3-channel input, 9x9
+    x = _rand((n, 3, h, w), 5)
+    w0 = _rand((32, 3, 9, 9), 6, 0.1)
+    b0 = _rand((32,), 7, 0.1)
+    g0 = E.ConvGeom(3, 32, 9, 1, 4)
+    r0 = FakeConv(w0.cuda(), b0.cuda(), g0)
+    # 32 -> 64 with PixelShuffle(2) on store
+    w1 = _rand((64, 32, 3, 3), 8, 0.08)
+    b1 = _rand((64,), 9, 0.1)
+    g1 = E.ConvGeom(32, 64, 3, 1, 1, shuffle2=True)
+    r1 = FakeConv(w1.cuda(), b1.cuda(), g1)
+    # 16 -> 3, NCHW + tanh
+    w2 = _rand((3, 16, 3, 3), 10, 0.15)
+    b2 = _rand((3,), 11, 0.1)
+    g2 = E.ConvGeom(16, 3, 3, 1, 1)
+    r2 = FakeConv(w2.cuda(), b2.cuda(), g2)
+    preps, keep = E.prepare_weights([(r0, n, h, w), (r1, n, h, w), (r2, n, 2 * h, 2 * w)], training=True)
+    slope = torch.tensor([0.3], device='cuda')
+    xin = x.cuda()
+    y0, sp, cp = E.conv_forward(preps[0], E.Operand.plain(xin, dims=(n, h, w, 3), mode=L.X_NCHW), bias=r0.bias,
+                                stats=True)
+    ref0 = F.conv2d(x, w0, b0, padding=4)
+    assert maxrel(nchw(y0), ref0) < TOL
+    # statistics of y0
+    bn = torch.nn.BatchNorm2d(32).cuda()
+    k = E.bn_finalize(sp, cp, bn)
+    mean = ref0.mean(dim=(0, 2, 3))
+    var = ref0.var(dim=(0, 2, 3), unbiased=False)
+    assert maxrel(k[2], mean) < 1e-4 and maxrel(k[3], torch.rsqrt(var + 1e-5)) < 1e-4
+    assert maxrel(bn.running_var, 0.9 + 0.1 * ref0.var(dim=(0, 2, 3), unbiased=True)) < 1e-4
+    # BN apply + PReLU prologue, PixelShuffle store
+    y1, _, _ = E.conv_forward(preps[1], E.Operand.affine_act(y0, k[0], k[1], slope), bias=r1.bias)
+    a0 = F.batch_norm(ref0, None, None, bn.weight.cpu(), bn.bias.cpu(), True, 0.1, 1e-5)
+    a0 = torch.where(a0 > 0, a0, 0.3 * a0)
+    ref1 = F.pixel_shuffle(F.conv2d(a0, w1, b1, padding=1), 2)
+    assert tuple(y1.shape) == (n, 2 * h, 2 * w, 16)
+    assert maxrel(nchw(y1), ref1) < TOL
+    y2, _, _ = E.conv_forward(preps[2], E.Operand.act(y1, slope), bias=r2.bias, y_mode=L.Y_NCHW, epi=L.EPI_TANH)
+    ref2 = torch.tanh(F.conv2d(torch.where(ref1 > 0, ref1, 0.3 * ref1), w2, b2, padding=1))
+    assert maxrel(y2, ref2) < TOL
+
+
+def test_spectral_norm_prepare_and_grad(E, L):
+    cout, cin, k, n, h, w = 64, 32, 3, 2, 8, 8
+    wt = _rand((cout, cin, k, k), 20, 0.1)
+    b = _rand((cout,), 21, 0.1)
+    u = F.normalize(_rand((cout,), 22), dim=0)
+    v = F.normalize(_rand((cin * k * k,), 23), dim=0)
+    x = _rand((n, cin, h, w), 24)
+    # CPU: legacy spectral norm algorithm
+    wr = wt.clone().requires_grad_(True)
+    wm = wr.reshape(cout, -1)
+    with torch.no_grad():
+        v1 = F.normalize(torch.mv(wm.t(), u), dim=0, eps=1e-12)
+        u1 = F.normalize(torch.mv(wm, v1), dim=0, eps=1e-12)
+    sigma = torch.dot(u1, torch.mv(wm, v1))
+    y_ref = F.conv2d(x, wr / sigma, b, padding=1)
+    r = _rand(tuple(y_ref.shape), 25)
+    (y_ref * r).sum().backward()
+    geom = E.ConvGeom(cin, cout, k, 1, 1)
+    ref = FakeConv(wt.cuda(), b.cuda(), geom, u.cuda(), v.cuda())
+    preps, keep = E.prepare_weights([(ref, n, h, w)], training=True)
+    p = preps[0]
+    assert maxrel(ref.u, u1) < 1e-5 and maxrel(ref.v, v1) < 1e-5 and maxrel(p.sigma, sigma.reshape(1)) < 1e-5
+    y, _, _ = E.conv_forward(p, E.Operand.plain(nhwc(x).cuda()), bias=ref.bias)
+    assert maxrel(nchw(y), y_ref) < TOL
+    red = E.conv_wgrad(p, E.Operand.plain(nhwc(x).cuda()), E.Operand.plain(nhwc(r).cuda()))
+    wg = E.WeightGradBatch()
+    wg.add(p, red)
+    gw, gb = wg.run()[id(ref)]
+    assert maxrel(gw, wr.grad) < TOL
+    # eval mode: no power iteration
+    ref2 = FakeConv(wt.cuda(), b.cuda(), geom, u.cuda(), v.cuda())
+    preps2, _ = E.prepare_weights([(ref2, n, h, w)], training=False)
+    assert torch.equal(ref2.u.cpu(), u) and maxrel(preps2[0].sigma, torch.dot(u, torch.mv(wt.reshape(cout, -1), v)).reshape(1)) < 1e-5
+
+
+def test_bn_backward_and_eltwise(E, L):
+    n, h, w, c = 2, 9, 7, 64
+    x = _rand((n, c, h, w), 30, 2.0)
+    dy = _rand((n, c, h, w), 31)
+    gamma = _rand((c,), 32) + 1.5
+    beta = _rand((c,), 33)
+    slope = 0.2
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    sl = torch.tensor([slope], requires_grad=True)
+    z = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    a = torch.where(z > 0, z, sl * z)
+    (a * dy).sum().backward()
+    mean = x.mean(dim=(0, 2, 3))
+    invstd = torch.rsqrt(x.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    k = torch.stack([scale, shift, mean, invstd]).cuda()
+    xd, dyd = nhwc(x).cuda(), nhwc(dy).cuda()
+    q, dgam, dbet, dsl = E.bn_backward(dyd, xd, k, gamma.cuda(), slope=torch.tensor([slope], device='cuda'))
+    assert maxrel(dgam, gr.grad) < TOL and maxrel(dbet, br.grad) < TOL and maxrel(dsl, sl.grad) < TOL
+    # dx through the BNACT_BWD prologue of a 1x1 identity conv
+    eye = torch.eye(c).reshape(c, c, 1, 1)
+    geom = E.ConvGeom(c, c, 1, 1, 0)
+    ref = FakeConv(eye.cuda(), None, geom)
+    preps, _ = E.prepare_weights([(ref, n, h, w)], training=True)
+    op = E.Operand(dyd, (n, h, w, c), pro=L.PRO_BNACT_BWD, x2=xd, pa=q[0], pb=q[1], pd=q[2], ps=k[0], pt=k[1],
+                   slope=torch.tensor([slope], device='cuda'))
+    dx, _, _ = E.conv_forward(preps[0], op)
+    assert maxrel(nchw(dx), xr.grad) < TOL
+    y = E.eltwise_res_affine(xd, 0.25, dyd, k[0], k[1])
+    ref_y = torch.where(x > 0, x, 0.25 * x) + dy * scale[None, :, None, None] + shift[None, :, None, None]
+    assert maxrel(nchw(y), ref_y) < 1e-6
+    out = E.prelu_slope_grad(dyd, xd)
+    assert maxrel(out, (dy * x)[x <= 0].sum().reshape(1)) < TOL
+
+
+def test_bicubic_against_golden(L, golden_dir):
+    z = np.load(golden_dir + '/bicubic.npz')
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for i in range(int(z['n'])):
+        x = torch.from_numpy(z['x%d' % i]).cuda()
+        oh, ow = (int(v) for v in z['size%d' % i])
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, oh, ow), device='cuda')
+        L.check(lib.sisr_bicubic_fwd(x.data_ptr(), y.data_ptr(), n * c, h, w, oh, ow, 0, st), 'bicubic')
+        assert float((y.cpu() - torch.from_numpy(z['interp%d' % i])).abs().max()) < 5e-6
+        L.check(lib.sisr_bicubic_fwd(x.data_ptr(), y.data_ptr(), n * c, h, w, oh, ow, 1, st), 'bicubic')
+        assert float((y.cpu() - torch.from_numpy(z['lr%d' % i])).abs().max()) < 5e-6
+        dy = torch.from_numpy(z['r%d' % i]).cuda()
+        dx = torch.empty_like(x)
+        L.check(lib.sisr_bicubic_bwd(dy.data_ptr(), None, dx.data_ptr(), n * c, h, w, oh, ow, st), 'bicubic_bwd')
+        assert float((dx.cpu() - torch.from_numpy(z['grad_x%d' % i])).abs().max()) < 2e-5
