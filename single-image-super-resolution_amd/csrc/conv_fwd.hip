@@ -19,7 +19,31 @@
 #include <algorithm>
 #include <cstring>
 
-template <int MSUB, int NSUB>
+template <int MSUB, int NSUB, int KU>
+__device__ __forceinline__ void conv_kblock(const float* const (&ap)[MSUB], const float* const (&bp)[NSUB], int k0,
+                                            f32x16 (&acc)[MSUB][NSUB]) {
+    float a[KU][MSUB], b[KU][NSUB];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+#pragma unroll
+        for (int ms = 0; ms < MSUB; ++ms) a[u][ms] = ap[ms][k0 + 2 * u];
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) b[u][ns] = bp[ns][k0 + 2 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u)
+#pragma unroll
+        for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns) acc[ms][ns] = mfma32(a[u][ms], b[u][ns], acc[ms][ns]);
+    // pin the schedule: all LDS reads of the block first, then the MFMAs (counted lgkmcnt waits)
+    __builtin_amdgcn_sched_group_barrier(0x100, KU * (MSUB + NSUB), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, KU * MSUB * NSUB, 0);
+}
+
+// TAG only changes the kernel SYMBOL: TAG 1 = the 3x3, 64->64, stride-1 trunk convolution of G (fwd and
+// dgrad, 66 identical launches per training step), so that profiler per-kernel averages refer to one shape.
+template <int MSUB, int NSUB, int TAG>
 __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_f32_kernel(const SisrConvDesc d) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const SisrConvPlan& p = d.plan;
@@ -88,10 +112,12 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_f32_kernel(const Sisr
     ov.N = d.N; ov.H = d.H; ov.W = d.W; ov.C = d.Cin;
     ov.mode = d.x_mode; ov.pro = d.pro_mode;
     ov.slope = d.pro_slope_p ? d.pro_slope_p[0] : d.pro_slope;
-    const bool vec_ok = (d.x_mode != SISR_X_NCHW) && !(p.CK & 3) && !(d.Cin & 3) &&
+    const bool vec_ok = (d.x_mode != SISR_X_NCHW) && !(p.CK & 3) && !((p.CK >> 2) & ((p.CK >> 2) - 1)) && !(d.Cin & 3) &&
                         !(d.x_mode == SISR_X_NHWC_UNSHUFFLE2 && ((d.Cin >> 2) & 3));
     const int iy_org = oy0 * S - d.pad_y, ix_org = ox0 * S - d.pad_x;
-    const int n4w = (BN * p.KROWP) >> 2;
+    const int kr4 = p.KROWP >> 2;
+    int wlg = 0;
+    while ((1 << wlg) < kr4) ++wlg;
 
     for (int chunk = 0; chunk < p.n_chunk; ++chunk) {
         __syncthreads();   // all MFMA reads of the previous chunk are done
@@ -99,14 +125,16 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_f32_kernel(const Sisr
                            1 << 30, 8);
         for (int r = 0; r < d.KH; ++r) {
             if (r > 0) __syncthreads();   // reads of the previous filter row's weights are done
-            {   // packed weights of (chunk, r): [BN][KROWP] contiguous -> LDS [BN][WSTR]
+            {   // packed weights of (chunk, r): [BN][KROWP] contiguous -> LDS [BN][WSTR]; 2^wlg lanes per row
                 const f32x4* src = reinterpret_cast<const f32x4*>(
                     d.wpk + ((int64_t)(chunk * d.KH + r) * p.CoutPad + cout_base) * p.KROWP);
-                for (int i = tid; i < n4w; i += SISR_BLOCK) {
-                    const f32x4 v = src[i];
-                    const int e = i * 4, j = e / p.KROWP, k = e - j * p.KROWP;
-                    float* dst = lds_w + j * WSTR + k;
-                    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+                const int k4 = tid & ((1 << wlg) - 1);
+                if (k4 < kr4) {
+                    for (int j = tid >> wlg; j < BN; j += SISR_BLOCK >> wlg) {
+                        const f32x4 v = src[j * kr4 + k4];
+                        float* dst = lds_w + j * WSTR + k4 * 4;
+                        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+                    }
                 }
             }
             __syncthreads();
@@ -116,18 +144,11 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_f32_kernel(const Sisr
             for (int ms = 0; ms < MSUB; ++ms) ap[ms] = lds_in + a_base[ms] + r * IW * p.PS + kk;
 #pragma unroll
             for (int ns = 0; ns < NSUB; ++ns) bp[ns] = lds_w + (ns * 32 + l31) * WSTR + kk;
-
-            for (int k0 = 0; k0 < p.KROWP; k0 += 2) {
-                float a[MSUB], b[NSUB];
-#pragma unroll
-                for (int ms = 0; ms < MSUB; ++ms) a[ms] = ap[ms][k0];
-#pragma unroll
-                for (int ns = 0; ns < NSUB; ++ns) b[ns] = bp[ns][k0];
-#pragma unroll
-                for (int ms = 0; ms < MSUB; ++ms)
-#pragma unroll
-                    for (int ns = 0; ns < NSUB; ++ns) acc[ms][ns] = mfma32(a[ms], b[ns], acc[ms][ns]);
-            }
+            // K loop in register blocks: all LDS reads of KU K-steps are issued, then their MFMAs (the
+            // compiler emits counted lgkmcnt waits), so LDS latency is exposed once per 4*KU MFMAs.
+            int k0 = 0;
+            for (; k0 + 8 <= p.KROWP; k0 += 8) conv_kblock<MSUB, NSUB, 4>(ap, bp, k0, acc);
+            for (; k0 < p.KROWP; k0 += 4) conv_kblock<MSUB, NSUB, 2>(ap, bp, k0, acc);   // KROWP % 4 == 0
         }
     }
     __syncthreads();   // LDS (weights region) is reused as reduction scratch below
@@ -253,47 +274,68 @@ extern "C" int sisr_conv2d_plan(SisrConvDesc* d) {
     SisrConvPlan& p = d->plan;
     std::memset(&p, 0, sizeof(p));
     const int64_t ypix = std::max((int64_t)d->N * d->y_H * d->y_W, (int64_t)d->N * d->Ho * d->Wo);
-    if (ypix * d->Cout >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 40))
+    if (ypix * d->Cout >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 31))
         return SISR_E_TOOBIG;
     p.nsub = d->Cout <= 32 ? 1 : 2;
     const int BN = p.nsub * 32;
     p.CoutPad = round_up(d->Cout, BN);
     const int64_t out_pix = (int64_t)d->N * d->Ho * d->Wo;
-    // BM = 256 pixels per workgroup unless the problem is too small to fill 256 CUs twice
-    p.msub = (out_pix * (p.CoutPad / BN) >= 256ll * 512) ? 2 : 1;
-    const int BM = 4 * p.msub * 32;
     const int S = d->stride;
-
     const int ck_opts[4] = {32, 16, 8, 4};
-    int best_lds = 1 << 30;
-    double best_score = -1.0;
-    for (int pass = 0; pass < 2 && best_score < 0; ++pass) {
-        const int lds_cap = pass == 0 ? 80 * 1024 : 160 * 1024;
-        for (int oi = 0; oi < 4; ++oi) {
-            int CK = d->Cin <= 32 ? d->Cin : ck_opts[oi];
-            if (d->Cin <= 32 && oi > 0) break;
-            const int PS = CK | 1;
-            const int KROWP = round_up(d->KW * PS, 4);
-            for (int TW = 1; TW <= std::min(d->Wo, BM); ++TW) {
-                const int TH = std::min(d->Ho, BM / TW);
-                int TN = 1;
-                if (TH == d->Ho && TW == d->Wo) TN = std::max(1, std::min(d->N, BM / (TH * TW)));
-                const int lds = conv_lds_bytes(BM, TN, TH, TW, S, d->KH, d->KW, PS, KROWP, BN);
-                if (lds > lds_cap) continue;
-                const int ty = (d->Ho + TH - 1) / TH, tx = (d->Wo + TW - 1) / TW, ngr = (d->N + TN - 1) / TN;
-                const double eff = (double)out_pix / ((double)ty * tx * ngr * BM);
-                const double halo = (double)(TH * TW) * S * S /
-                                    ((double)((TH - 1) * S + d->KH) * ((TW - 1) * S + d->KW));
-                // MFMA efficiency of the K padding and a mild preference for larger chunks
-                const double keff = (double)(d->KW * CK) / KROWP;
-                const double score = eff * (0.75 + 0.25 * halo) * (0.5 + 0.5 * keff);
-                if (score > best_score + 1e-9) {
-                    best_score = score; best_lds = lds;
-                    p.TH = TH; p.TW = TW; p.TN = TN; p.tiles_y = ty; p.tiles_x = tx; p.n_groups = ngr;
-                    p.CK = CK; p.PS = PS; p.KROWP = KROWP;
+    // For each workgroup height (BM = 256 or 128 pixels) find the best tile shape, then keep the
+    // height whose last wave of workgroups wastes least: cost = ceil(blocks / 256 CUs) * BM.
+    SisrConvPlan cand[2];
+    int cand_lds[2] = {0, 0};
+    double cand_cost[2] = {1e30, 1e30};
+    for (int mi = 0; mi < 2; ++mi) {
+        const int msub = 2 - mi;
+        const int BM = 4 * msub * 32;
+        SisrConvPlan q = p;
+        q.msub = msub;
+        int best_lds = 1 << 30;
+        double best_score = -1.0;
+        for (int pass = 0; pass < 2 && best_score < 0; ++pass) {
+            const int lds_cap = pass == 0 ? 80 * 1024 : 160 * 1024;
+            for (int oi = 0; oi < 4; ++oi) {
+                int CK = d->Cin <= 32 ? d->Cin : ck_opts[oi];
+                if (d->Cin <= 32 && oi > 0) break;
+                const int PS = CK | 1;
+                const int KROWP = round_up(d->KW * PS, 4);
+                for (int TW = 1; TW <= std::min(d->Wo, BM); ++TW) {
+                    const int TH = std::min(d->Ho, BM / TW);
+                    int TN = 1;
+                    if (TH == d->Ho && TW == d->Wo) TN = std::max(1, std::min(d->N, BM / (TH * TW)));
+                    const int lds = conv_lds_bytes(BM, TN, TH, TW, S, d->KH, d->KW, PS, KROWP, BN);
+                    if (lds > lds_cap) continue;
+                    const int ty = (d->Ho + TH - 1) / TH, tx = (d->Wo + TW - 1) / TW, ngr = (d->N + TN - 1) / TN;
+                    const double eff = (double)out_pix / ((double)ty * tx * ngr * BM);
+                    const double halo = (double)(TH * TW) * S * S /
+                                        ((double)((TH - 1) * S + d->KH) * ((TW - 1) * S + d->KW));
+                    const double keff = (double)(d->KW * CK) / KROWP;
+                    const double score = eff * (0.75 + 0.25 * halo) * (0.5 + 0.5 * keff);
+                    if (score > best_score + 1e-9) {
+                        best_score = score; best_lds = lds;
+                        q.TH = TH; q.TW = TW; q.TN = TN; q.tiles_y = ty; q.tiles_x = tx; q.n_groups = ngr;
+                        q.CK = CK; q.PS = PS; q.KROWP = KROWP;
+                    }
                 }
+                if (best_score >= 0 && pass == 0 && d->Cin > 32) break;   // largest chunk that fits wins
             }
-            if (best_score >= 0 && pass == 0 && d->Cin > 32) break;   // largest chunk that fits wins
+        }
+        if (best_score < 0) continue;
+        const int64_t blocks = (int64_t)q.tiles_y * q.tiles_x * q.n_groups * (p.CoutPad / BN);
+        cand[mi] = q;
+        cand_lds[mi] = best_lds;
+        cand_cost[mi] = (double)((blocks + 255) / 256) * BM * (mi == 0 ? 1.0 : 1.02);
+    }
+    double best_score = -1.0;
+    int best_lds = 0;
+    {
+        const int pick = cand_cost[1] < cand_cost[0] ? 1 : 0;
+        if (cand_cost[pick] < 1e29) {
+            p = cand[pick];
+            best_lds = cand_lds[pick];
+            best_score = 1.0;
         }
     }
     if (best_score < 0) return SISR_E_TOOBIG;
@@ -304,17 +346,17 @@ extern "C" int sisr_conv2d_plan(SisrConvDesc* d) {
     return 0;
 }
 
-template <int MSUB, int NSUB>
+template <int MSUB, int NSUB, int TAG>
 static int launch_conv(const SisrConvDesc* d, hipStream_t st) {
     static int lds_max = 64 * 1024;   // raise the dynamic-LDS cap only when a plan needs it
     if (d->plan.lds_bytes > lds_max) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<MSUB, NSUB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<MSUB, NSUB, TAG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, d->plan.lds_bytes);
         if (e != hipSuccess) return (int)e;
         lds_max = d->plan.lds_bytes;
     }
     const dim3 grid(d->plan.n_tiles, d->plan.CoutPad / (NSUB * 32));
-    hipLaunchKernelGGL((conv_mfma_f32_kernel<MSUB, NSUB>), grid, dim3(SISR_BLOCK), d->plan.lds_bytes, st, *d);
+    hipLaunchKernelGGL((conv_mfma_f32_kernel<MSUB, NSUB, TAG>), grid, dim3(SISR_BLOCK), d->plan.lds_bytes, st, *d);
     SISR_CHECK_LAUNCH();
     return 0;
 }
@@ -327,9 +369,10 @@ extern "C" int sisr_conv2d_f32(const SisrConvDesc* d, void* stream) {
     const SisrConvPlan& p = d->plan;
     if (p.n_tiles <= 0 || p.lds_bytes <= 0 || p.lds_bytes > 160 * 1024) return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (p.msub == 2 && p.nsub == 2) return launch_conv<2, 2>(d, st);
-    if (p.msub == 2 && p.nsub == 1) return launch_conv<2, 1>(d, st);
-    if (p.msub == 1 && p.nsub == 2) return launch_conv<1, 2>(d, st);
-    if (p.msub == 1 && p.nsub == 1) return launch_conv<1, 1>(d, st);
+    const bool trunk = d->Cin == 64 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1;
+    if (p.msub == 2 && p.nsub == 2) return trunk ? launch_conv<2, 2, 1>(d, st) : launch_conv<2, 2, 0>(d, st);
+    if (p.msub == 2 && p.nsub == 1) return launch_conv<2, 1, 0>(d, st);
+    if (p.msub == 1 && p.nsub == 2) return trunk ? launch_conv<1, 2, 1>(d, st) : launch_conv<1, 2, 0>(d, st);
+    if (p.msub == 1 && p.nsub == 1) return launch_conv<1, 1, 0>(d, st);
     return SISR_E_BADARG;
 }

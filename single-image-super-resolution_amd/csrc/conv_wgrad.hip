@@ -19,6 +19,27 @@
 
 #define WG_NACC 9
 
+// one K-step = 2 pixels: NACC A operands (one per (filter row, row tile)) against one B operand
+template <int NACC, int KU>
+__device__ __forceinline__ void wgrad_kblock(const float* ip, const float* dyp, const int (&aoff)[NACC], int istep,
+                                             int dstep, f32x16 (&acc)[NACC]) {
+    float a[KU][NACC], b[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        b[u] = dyp[u * dstep];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) a[u][i] = ip[u * istep + aoff[i]];
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u)
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = mfma32(a[u][i], b[u], acc[i]);
+    // pin the schedule: all LDS reads of the block first, then the MFMAs (counted lgkmcnt waits)
+    __builtin_amdgcn_sched_group_barrier(0x100, KU * (NACC + 1), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, KU * NACC, 0);
+}
+
+template <int NACC>
 __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_f32_kernel(const SisrWgradDesc d) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -32,7 +53,6 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_f32_kernel(const Sis
     const int jsub = wave % d.NJ, ppart = wave / d.NJ;
     const int q = blockIdx.y % d.n_chunk, cot = blockIdx.y / d.n_chunk;
     const int co_base = cot * DSTR;
-    const int nacc = d.KH * d.NT;
 
     float* lds_in = smem;
     float* lds_dy = smem + ((in_elems + 64 + 3) & ~3);
@@ -44,20 +64,20 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_f32_kernel(const Sis
     og.x1 = d.g1; og.x2 = d.g2; og.pa = d.qa; og.pb = d.qb; og.pd = d.qd; og.ps = d.qs; og.pt = d.qt;
     og.N = d.N; og.H = d.Ho; og.W = d.Wo; og.C = d.Cout; og.mode = d.g_mode; og.pro = d.gpro_mode;
     og.slope = d.gpro_slope_p ? d.gpro_slope_p[0] : d.gpro_slope;
-    const bool xvec = (d.x_mode != SISR_X_NCHW) && !(d.CK & 3) && !(d.Cin & 3) &&
+    const bool xvec = (d.x_mode != SISR_X_NCHW) && !(d.CK & 3) && !((d.CK >> 2) & ((d.CK >> 2) - 1)) && !(d.Cin & 3) &&
                       !(d.x_mode == SISR_X_NHWC_UNSHUFFLE2 && ((d.Cin >> 2) & 3));
     const bool gvec = (d.g_mode != SISR_X_NCHW) && !(d.Cout & 3) &&
                       !(d.g_mode == SISR_X_NHWC_UNSHUFFLE2 && ((d.Cout >> 2) & 3));
 
-    int aoff[WG_NACC];
+    int aoff[NACC];
 #pragma unroll
-    for (int a = 0; a < WG_NACC; ++a) {
+    for (int a = 0; a < NACC; ++a) {
         const int r = a / d.NT, tt = a - r * d.NT;
         aoff[a] = r * IW * d.PS + tt * d.TSTEP;
     }
-    f32x16 acc[WG_NACC];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int a = 0; a < WG_NACC; ++a)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
     float bias_acc = 0.f;
@@ -85,31 +105,28 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_f32_kernel(const Sis
             const int tn = row / d.TH, ty = row - tn * d.TH;
             const float* dyp = lds_dy + (row * TWp + kk) * DSTR + jsub * 32 + l31;
             const float* inp = lds_in + ((tn * IH + ty * S) * IW + kk * S) * d.PS + l31;
-            for (int tx0 = 0; tx0 < TWp; tx0 += 2) {
-                const float bval = dyp[tx0 * DSTR];
-                const float* ip = inp + tx0 * S * d.PS;
-#pragma unroll
-                for (int a = 0; a < WG_NACC; ++a) {
-                    if (a < nacc) acc[a] = mfma32(ip[aoff[a]], bval, acc[a]);
-                }
-            }
+            const int istep = 2 * S * d.PS, dstep = 2 * DSTR;      // one K-step = 2 pixels
+            int tx0 = 0;
+            for (; tx0 + 4 <= TWp; tx0 += 4)
+                wgrad_kblock<NACC, 2>(inp + tx0 * S * d.PS, dyp + tx0 * DSTR, aoff, istep, dstep, acc);
+            if (tx0 < TWp) wgrad_kblock<NACC, 1>(inp + tx0 * S * d.PS, dyp + tx0 * DSTR, aoff, istep, dstep, acc);
         }
     }
 
     // ---- sum the pixel parts of each jsub through LDS (one round per extra part) -----------------
     __syncthreads();
     for (int k = 1; k < NP; ++k) {
-        float* buf = smem + (size_t)jsub * (WG_NACC * 16 * 64);
+        float* buf = smem + (size_t)jsub * (NACC * 16 * 64);
         if (ppart == k) {
 #pragma unroll
-            for (int a = 0; a < WG_NACC; ++a)
+            for (int a = 0; a < NACC; ++a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) buf[(a * 16 + i) * 64 + lane] = acc[a][i];
         }
         __syncthreads();
         if (ppart == 0) {
 #pragma unroll
-            for (int a = 0; a < WG_NACC; ++a)
+            for (int a = 0; a < NACC; ++a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[a][i] += buf[(a * 16 + i) * 64 + lane];
         }
@@ -120,8 +137,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_f32_kernel(const Sis
         float* sl = d.slab + (int64_t)blockIdx.x * d.slab_stride;
         const int kvalid = d.KW * d.PS;
 #pragma unroll
-        for (int a = 0; a < WG_NACC; ++a) {
-            if (a >= nacc) continue;
+        for (int a = 0; a < NACC; ++a) {
             const int r = a / d.NT, tt = a - r * d.NT;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -137,13 +153,25 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_f32_kernel(const Sis
         d.bias_slab[(int64_t)blockIdx.x * d.slab_stride + co_base + tid] = bias_acc;
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int n_slabs,
-                                   int64_t elems) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < n_slabs; ++k) s += slab[(int64_t)k * elems + i];
-        out[i] = s;
+// out[i] = sum_k slab[k][i]: 64 float4 columns x 4 slab-splits per workgroup, combined through LDS
+__global__ void __launch_bounds__(SISR_BLOCK) slab_reduce_kernel(const float* __restrict__ slab,
+                                                                float* __restrict__ out, int n_slabs,
+                                                                int64_t elems) {
+    __shared__ f32x4 sh[3][64];
+    const int col = threadIdx.x & 63, split = threadIdx.x >> 6;
+    const int64_t i4 = (int64_t)blockIdx.x * 64 + col;
+    const int64_t n4 = elems >> 2;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i4 < n4) {
+#pragma unroll 4
+        for (int k = split; k < n_slabs; k += 4)
+            s += *reinterpret_cast<const f32x4*>(slab + (int64_t)k * elems + i4 * 4);
+    }
+    if (split > 0) sh[split - 1][col] = s;
+    __syncthreads();
+    if (split == 0 && i4 < n4) {
+        s += sh[0][col] + sh[1][col] + sh[2][col];
+        *reinterpret_cast<f32x4*>(out + i4 * 4) = s;
     }
 }
 
@@ -152,6 +180,8 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 extern "C" int sisr_wgrad_plan(SisrWgradDesc* d, int32_t max_pixel_blocks) {
     if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0) return SISR_E_BADARG;
     if (d->stride != 1 && d->stride != 2) return SISR_E_BADARG;
+    if ((int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 31) || (int64_t)d->N * d->Ho * d->Wo * d->Cout >= (1ll << 31))
+        return SISR_E_TOOBIG;
     d->CK = d->Cin <= 32 ? d->Cin : 32;
     d->PS = d->CK | 1;
     d->KROWP = round_up(d->KW * d->PS, 4);
@@ -164,7 +194,7 @@ extern "C" int sisr_wgrad_plan(SisrWgradDesc* d, int32_t max_pixel_blocks) {
     d->NP = 4 / d->NJ;
     d->CoutPad = round_up(d->Cout, d->NJ * 32);
     const int S = d->stride, DSTR = d->NJ * 32;
-    const int red_bytes = d->NP > 1 ? d->NJ * WG_NACC * 16 * 64 * 4 : 0;
+    const int red_bytes = d->NP > 1 ? d->NJ * (d->KH * d->NT) * 16 * 64 * 4 : 0;
     double best = -1.0;
     for (int BMW = 128; BMW >= 32 && best < 0; BMW >>= 1) {
         for (int TW = 1; TW <= std::min(d->Wo, BMW); ++TW) {
@@ -200,6 +230,21 @@ extern "C" int sisr_wgrad_plan(SisrWgradDesc* d, int32_t max_pixel_blocks) {
     return 0;
 }
 
+template <int NACC>
+static int launch_wgrad(const SisrWgradDesc* d, hipStream_t st) {
+    static int lds_max = 64 * 1024;
+    if (d->lds_bytes > lds_max) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_f32_kernel<NACC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        lds_max = d->lds_bytes;
+    }
+    const dim3 grid(d->grid_x, d->n_chunk * (d->CoutPad / (d->NJ * 32)));
+    hipLaunchKernelGGL(wgrad_mfma_f32_kernel<NACC>, grid, dim3(SISR_BLOCK), d->lds_bytes, st, *d);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sisr_conv2d_wgrad_f32(const SisrWgradDesc* d, void* stream) {
     if (!d || !d->x1 || !d->g1 || !d->slab) return SISR_E_BADARG;
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
@@ -207,25 +252,27 @@ extern "C" int sisr_conv2d_wgrad_f32(const SisrWgradDesc* d, void* stream) {
     if (d->slab_stride < d->slab_elems) return SISR_E_BADARG;
     if (d->grid_x <= 0 || d->lds_bytes <= 0 || d->lds_bytes > 160 * 1024 || d->KH * d->NT > WG_NACC)
         return SISR_E_BADARG;
-    static int lds_max = 64 * 1024;
-    if (d->lds_bytes > lds_max) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_f32_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        lds_max = d->lds_bytes;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (d->KH * d->NT) {
+        case 1: return launch_wgrad<1>(d, st);
+        case 2: return launch_wgrad<2>(d, st);
+        case 3: return launch_wgrad<3>(d, st);
+        case 4: return launch_wgrad<4>(d, st);
+        case 5: return launch_wgrad<5>(d, st);
+        case 6: return launch_wgrad<6>(d, st);
+        case 7: return launch_wgrad<7>(d, st);
+        case 8: return launch_wgrad<8>(d, st);
+        case 9: return launch_wgrad<9>(d, st);
     }
-    const dim3 grid(d->grid_x, d->n_chunk * (d->CoutPad / (d->NJ * 32)));
-    hipLaunchKernelGGL(wgrad_mfma_f32_kernel, grid, dim3(SISR_BLOCK), d->lds_bytes,
-                       reinterpret_cast<hipStream_t>(stream), *d);
-    SISR_CHECK_LAUNCH();
-    return 0;
+    return SISR_E_UNSUPPORTED;
 }
 
 extern "C" int sisr_slab_reduce_f32(const float* slab, float* out, int32_t n_slabs, int64_t elems,
                                     void* stream) {
     if (!slab || !out || n_slabs <= 0 || elems <= 0) return SISR_E_BADARG;
-    const int blocks = (int)std::min<int64_t>((elems + 255) / 256, 2048);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    if (elems & 3) return SISR_E_BADARG;   // slab strides are multiples of 4 floats (16-byte loads)
+    const int blocks = (int)((elems / 4 + 63) / 64);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(SISR_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
                        slab, out, n_slabs, elems);
     SISR_CHECK_LAUNCH();
     return 0;

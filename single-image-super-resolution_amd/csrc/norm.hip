@@ -14,12 +14,13 @@ __global__ void __launch_bounds__(SISR_BLOCK) bn_finalize_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
     float* save_invstd) {
-    __shared__ double sh_n[4][64], sh_mean[4][64], sh_m2[4][64];
-    const int cl = threadIdx.x & 63, split = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    // 16 channels x 16 tile-splits per workgroup; splits merged pairwise through LDS
+    __shared__ double sh_n[16][16], sh_mean[16][16], sh_m2[16][16];
+    const int cl = threadIdx.x & 15, split = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double n = 0.0, mean = 0.0, m2 = 0.0;
     if (c < C) {
-        for (int t = split; t < n_tiles; t += 4) {
+        for (int t = split; t < n_tiles; t += 16) {
             const double nb = cnt_part[t];
             if (nb <= 0.0) continue;
             const double mb = stat_part[(int64_t)t * 2 * C + c];
@@ -32,15 +33,20 @@ __global__ void __launch_bounds__(SISR_BLOCK) bn_finalize_kernel(
     }
     sh_n[split][cl] = n; sh_mean[split][cl] = mean; sh_m2[split][cl] = m2;
     __syncthreads();
-    if (split == 0 && c < C) {
-        for (int k = 1; k < 4; ++k) {
-            const double nb = sh_n[k][cl];
-            if (nb <= 0.0) continue;
-            const double nn = n + nb, delta = sh_mean[k][cl] - mean;
-            mean += delta * (nb / nn);
-            m2 += sh_m2[k][cl] + delta * delta * (n * nb / nn);
-            n = nn;
+    for (int half = 8; half >= 1; half >>= 1) {
+        if (split < half) {
+            const double nb = sh_n[split + half][cl];
+            if (nb > 0.0) {
+                const double nn = n + nb, delta = sh_mean[split + half][cl] - mean;
+                mean += delta * (nb / nn);
+                m2 += sh_m2[split + half][cl] + delta * delta * (n * nb / nn);
+                n = nn;
+            }
+            sh_n[split][cl] = n; sh_mean[split][cl] = mean; sh_m2[split][cl] = m2;
         }
+        __syncthreads();
+    }
+    if (split == 0 && c < C) {
         const double var = m2 / n;                       // biased (normalisation)
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = gamma[c] * invstd;
@@ -112,15 +118,24 @@ __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_reduce_kernel(const SisrBnB
 }
 
 __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_finalize_kernel(const SisrBnBwdDesc d) {
+    // workgroup = 16 channels x 16 row-splits over the per-workgroup partial rows of the reduce kernel
+    __shared__ double sh1[16][16], sh2[16][16];
     __shared__ float scratch[8];
     const int stride = 2 * d.C + 1;
     const double inv_n = 1.0 / (double)d.P;
-    for (int c = threadIdx.x; c < d.C; c += SISR_BLOCK) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int b = 0; b < d.grid; ++b) {
+    const int cl = threadIdx.x & 15, split = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < d.C) {
+        for (int b = split; b < d.grid; b += 16) {
             s1 += d.work[(int64_t)b * stride + c];
             s2 += d.work[(int64_t)b * stride + d.C + c];
         }
+    }
+    sh1[split][cl] = s1; sh2[split][cl] = s2;
+    __syncthreads();
+    if (split == 0 && c < d.C) {
+        for (int k = 1; k < 16; ++k) { s1 += sh1[k][cl]; s2 += sh2[k][cl]; }
         const float ga = d.gamma[c], is = d.invstd[c], mu = d.mean[c];
         const float qa = ga * is;
         const float qb = (float)(-(double)ga * is * is * (s2 * inv_n));
@@ -130,7 +145,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_finalize_kernel(const SisrB
         d.dgamma[c] = (float)s2;
         d.dbeta[c] = (float)s1;
     }
-    if (d.dslope != nullptr) {
+    if (d.dslope != nullptr && blockIdx.x == 0) {
         float part = 0.f;
         for (int b = threadIdx.x; b < d.grid; b += SISR_BLOCK) part += d.work[(int64_t)b * stride + 2 * d.C];
         const float tot = block_sum(part, scratch);
@@ -202,7 +217,7 @@ extern "C" int sisr_bn_finalize(const float* stat_part, const float* cnt_part, i
     if (!stat_part || !cnt_part || n_tiles <= 0 || C <= 0 || !gamma || !beta || !running_mean || !running_var ||
         !scale || !shift || !save_mean || !save_invstd)
         return SISR_E_BADARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(SISR_BLOCK), 0, S_(stream), stat_part,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(SISR_BLOCK), 0, S_(stream), stat_part,
                        cnt_part, n_tiles, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
                        save_mean, save_invstd);
     SISR_CHECK_LAUNCH();
@@ -224,8 +239,8 @@ extern "C" int sisr_bn_bwd_plan(SisrBnBwdDesc* d) {
     const int G = d->C >> 2;
     if (G > SISR_BLOCK || (SISR_BLOCK % G) != 0) return SISR_E_UNSUPPORTED;
     const int PL = SISR_BLOCK / G;
-    const int64_t want = (d->P + (int64_t)PL * 8 - 1) / ((int64_t)PL * 8);   // >= 8 pixels per thread
-    d->grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 1024));
+    const int64_t want = (d->P + (int64_t)PL * 16 - 1) / ((int64_t)PL * 16);   // >= 16 pixels per thread
+    d->grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 512));
     return 0;
 }
 
@@ -238,7 +253,7 @@ extern "C" int sisr_bn_bwd(const SisrBnBwdDesc* d, void* stream) {
     if (lds > 64 * 1024) return SISR_E_UNSUPPORTED;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(d->grid), dim3(SISR_BLOCK), lds, S_(stream), *d);
     SISR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(SISR_BLOCK), 0, S_(stream), *d);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 15) / 16), dim3(SISR_BLOCK), 0, S_(stream), *d);
     SISR_CHECK_LAUNCH();
     return 0;
 }

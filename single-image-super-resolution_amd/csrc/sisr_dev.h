@@ -86,6 +86,88 @@ __host__ __device__ __forceinline__ bool operand_needs_x2(int pro) {
            pro == SISR_PRO_TANH_BWD;
 }
 
+// ---- lean float4 staging: prologue fixed at compile time, the thread's 4 channels are the same for
+// every item it stages (items advance by 64 lanes and G = CK/4 divides 64), so the per-channel
+// constants live in registers; addressing is 32-bit and row-relative.
+template <int PRO>
+__device__ __forceinline__ f32x4 apply4(const f32x4 a, const f32x4 b, const f32x4 ka, const f32x4 kb,
+                                        const f32x4 kd, const f32x4 ks, const f32x4 kt, const float slope) {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (PRO == SISR_PRO_NONE) v[j] = a[j];
+        else if (PRO == SISR_PRO_ACT) v[j] = lrelu(a[j], slope);
+        else if (PRO == SISR_PRO_AFFINE_ACT) v[j] = lrelu(ka[j] * a[j] + kd[j], slope);
+        else if (PRO == SISR_PRO_BNBWD) v[j] = ka[j] * a[j] + kb[j] * b[j] + kd[j];
+        else if (PRO == SISR_PRO_BNACT_BWD) {
+            const float z = ks[j] * b[j] + kt[j];
+            const float g = z > 0.f ? a[j] : slope * a[j];
+            v[j] = ka[j] * g + kb[j] * b[j] + kd[j];
+        } else if (PRO == SISR_PRO_ACT_BWD) v[j] = b[j] > 0.f ? a[j] : slope * a[j];
+        else v[j] = a[j] * (1.f - b[j] * b[j]);
+    }
+    return v;
+}
+
+template <int PRO>
+__device__ __forceinline__ void stage_tile_vec(const OperandView& o, float* lds, int PS, int CK, int c0,
+                                               int TN, int IH, int IW, int n0, int iy_org, int ix_org,
+                                               int valid_w) {
+    constexpr bool need2 = PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD || PRO == SISR_PRO_ACT_BWD ||
+                           PRO == SISR_PRO_TANH_BWD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = CK >> 2;
+    int lg = 0;
+    while ((1 << lg) < G) ++lg;
+    const int g = lane & (G - 1);
+    const int c = c0 + g * 4;
+    const bool c_ok = c < o.C;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ka = zero, kb = zero, kd = zero, ks = zero, kt = zero;
+    if (c_ok) {
+        if (PRO == SISR_PRO_AFFINE_ACT || PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD) {
+            ka = *reinterpret_cast<const f32x4*>(o.pa + c);
+            kd = *reinterpret_cast<const f32x4*>(o.pd + c);
+        }
+        if (PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD) kb = *reinterpret_cast<const f32x4*>(o.pb + c);
+        if (PRO == SISR_PRO_BNACT_BWD) {
+            ks = *reinterpret_cast<const f32x4*>(o.ps + c);
+            kt = *reinterpret_cast<const f32x4*>(o.pt + c);
+        }
+    }
+    // physical layout of the tensor behind the logical (N,H,W,C) view
+    int coff = c, ysh = 0, xsh = 0, Cp = o.C, Wp = o.W, Hp = o.H, mul = 1;
+    if (o.mode == SISR_X_NHWC_UNSHUFFLE2) {
+        const int Cq = o.C >> 2;
+        const int ij = c / Cq;
+        coff = c - ij * Cq; ysh = ij >> 1; xsh = ij & 1; Cp = Cq; Wp = 2 * o.W; Hp = 2 * o.H; mul = 2;
+    }
+    const int xstep = mul * Cp;
+    const int row_items = IW << lg;
+    for (int row = wave; row < TN * IH; row += SISR_BLOCK / 64) {
+        const int tn = row / IH, iyl = row - tn * IH;
+        const int n = n0 + tn, iy = iy_org + iyl;
+        const bool row_ok = c_ok && n < o.N && iy >= 0 && iy < o.H;
+        const int rbase = ((n * Hp + iy * mul + ysh) * Wp + xsh) * Cp + coff;
+        float* lrow = lds + row * IW * PS;
+        for (int item = lane; item < row_items; item += 64) {
+            const int ixl = item >> lg;
+            const int ix = ix_org + ixl;
+            f32x4 v = zero;
+            if (row_ok && ix >= 0 && ix < o.W && ixl < valid_w) {
+                const int off = rbase + ix * xstep;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(o.x1 + off);
+                f32x4 b = zero;
+                if (need2) b = *reinterpret_cast<const f32x4*>(o.x2 + off);
+                v = apply4<PRO>(a, b, ka, kb, kd, ks, kt, o.slope);
+            }
+            float* dst = lrow + ixl * PS + g * 4;
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+            if (g == 0 && PS > CK) lrow[ixl * PS + CK] = 0.f;
+        }
+    }
+}
+
 // Stage one channel chunk of an input halo tile into LDS as [pixel][PS] (PS odd => conflict-free
 // per-lane b32 reads with lanes on consecutive pixels), applying the operand's prologue.  Pixels
 // outside the image and channel slots >= CK (the pad slot) are written as 0.
@@ -96,31 +178,21 @@ __device__ __forceinline__ void stage_operand_tile(const OperandView& o, float* 
                                                    int ix_org, bool vec_ok, int valid_w, int slack) {
     const int tid = threadIdx.x;
     const int npix = TN * IH * IW;
-    const bool need2 = operand_needs_x2(o.pro);
     if (vec_ok) {
-        const int G = CK >> 2;
-        const int items = npix * G;
-        for (int it = tid; it < items; it += SISR_BLOCK) {
-            const int pix = it / G, g = it - pix * G;
-            const int tn = pix / (IH * IW), rem = pix - tn * (IH * IW);
-            const int iyl = rem / IW, ixl = rem - iyl * IW;
-            const int n = n0 + tn, iy = iy_org + iyl, ix = ix_org + ixl;
-            const int c = c0 + g * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < o.N && iy >= 0 && iy < o.H && ix >= 0 && ix < o.W && c < o.C && ixl < valid_w) {
-                const int64_t off = operand_offset(o, n, iy, ix, c);
-                const f32x4 a = *reinterpret_cast<const f32x4*>(o.x1 + off);
-                f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (need2) b = *reinterpret_cast<const f32x4*>(o.x2 + off);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = operand_apply(o, a[j], b[j], c + j);
-            }
-            float* dst = lds + pix * PS + g * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dst[j] = v[j];
-            if (g == 0 && PS > CK) lds[pix * PS + CK] = 0.f;
+        switch (o.pro) {
+#define SISR_STAGE_CASE(P) \
+    case P: stage_tile_vec<P>(o, lds, PS, CK, c0, TN, IH, IW, n0, iy_org, ix_org, valid_w); break;
+            SISR_STAGE_CASE(SISR_PRO_NONE)
+            SISR_STAGE_CASE(SISR_PRO_ACT)
+            SISR_STAGE_CASE(SISR_PRO_AFFINE_ACT)
+            SISR_STAGE_CASE(SISR_PRO_BNBWD)
+            SISR_STAGE_CASE(SISR_PRO_BNACT_BWD)
+            SISR_STAGE_CASE(SISR_PRO_ACT_BWD)
+            SISR_STAGE_CASE(SISR_PRO_TANH_BWD)
+#undef SISR_STAGE_CASE
         }
     } else {
+        const bool need2 = operand_needs_x2(o.pro);
         const int items = npix * PS;
         for (int it = tid; it < items; it += SISR_BLOCK) {
             const int pix = it / PS, cs = it - pix * PS;
@@ -140,4 +212,3 @@ __device__ __forceinline__ void stage_operand_tile(const OperandView& o, float* 
     }
     if (tid < slack) lds[npix * PS + tid] = 0.f;   // slack read by zero-weight / masked K tails
 }
-

@@ -1,0 +1,68 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sisr_hip.h declares; the host
+planners (pure host code) produce valid plans; the product refuses CPU tensors (no fallback)."""
+import ctypes
+import importlib
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pkg(sub):
+    return importlib.import_module('single-image-super-resolution_amd.' + sub)
+
+
+def test_library_exports_every_declared_symbol():
+    L = _pkg('_lib')
+    if not os.path.exists(L.LIB_PATH):
+        L.build()
+    hdr = open(os.path.join(ROOT, 'include', 'sisr_hip.h')).read()
+    declared = set(re.findall(r'\b(sisr_[a-z0-9_]+)\s*\(', hdr))
+    lib = ctypes.CDLL(L.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    assert L.lib().sisr_version().startswith(b'sisr_hip')          # also checks the struct mirror
+
+
+@pytest.mark.parametrize('shape', [(16, 64, 64, 3, 1, 96, 96), (16, 3, 64, 9, 1, 96, 96), (16, 64, 256, 3, 1, 96, 96),
+                                   (16, 64, 3, 3, 1, 192, 192), (16, 256, 256, 3, 2, 24, 24), (2, 1, 3, 3, 1, 5, 7)])
+def test_planners_fit_lds_and_cover_the_problem(shape):
+    E = _pkg('engine')
+    n, cin, cout, k, s, h, w = shape
+    f, d, g = E.ConvGeom(cin, cout, k, s, k // 2).plans(n, h, w)
+    for pl, (ho, wo) in ((f, (f.Ho, f.Wo)),) + (((d, (d.Ho, d.Wo)),) if d is not None else ()):
+        p = pl.plan
+        assert 0 < p.lds_bytes <= 160 * 1024
+        assert p.tiles_y * p.TH >= ho and p.tiles_x * p.TW >= wo and p.n_groups * p.TN >= n
+        assert p.TN * p.TH * p.TW <= 4 * p.msub * 32
+        assert p.PS % 2 == 1 and p.KROWP % 4 == 0 and p.KROWP >= pl.KW * p.PS
+        assert p.n_chunk * p.CK >= pl.Cin and p.CoutPad % (32 * p.nsub) == 0
+    assert 0 < g.lds_bytes <= 160 * 1024 and g.KH * g.NT <= 9 and g.NJ * g.NP == 4
+    assert g.tiles_y * g.TH >= g.Ho and g.tiles_x * g.TW >= g.Wo and 1 <= g.grid_x <= g.n_tiles
+
+
+def test_cpu_tensors_are_refused():
+    mg, ut = _pkg('model_generator'), _pkg('utils')
+    with pytest.raises(RuntimeError):
+        mg.Generator(1, 16, 64, [2])(torch.zeros(1, 3, 8, 8))
+    with pytest.raises(RuntimeError):
+        ut.lr_from_hr(torch.zeros(1, 3, 8, 8), (4, 4))
+
+
+def test_modules_mirror_reference_state_dict_layout():
+    """key names / order of the reference's state_dict (captured in the golden fixtures)."""
+    import numpy as np
+    mg, mp_ = _pkg('model_generator'), _pkg('model_generator_progressive')
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'gen_x4_suffix_w32.npz'))
+    keys = [k[6:] for k in z.files if k.startswith('state/')]
+    g = mg.GeneratorSuffix(mg.Generator(1, 32, 128, [2], use_sn=True))
+    assert list(g.state_dict().keys()) == keys
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'prog_x8_w64.npz'))
+    keys = [k[6:] for k in z.files if k.startswith('state/')]
+    g1 = mp_.GeneratorSuffix(mp_.GeneratorProgresiveBase(1, 64), 64)
+    g3 = mp_.GeneratorSuffix(mp_.GeneratorSuffix(g1.beginning, 16).beginning, 4)
+    assert list(g3.state_dict().keys()) == keys
