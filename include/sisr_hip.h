@@ -137,6 +137,12 @@ typedef struct SisrWeightDesc {
     int32_t f_CK, f_PS, f_KROWP, f_n_chunk, f_CoutPad;
     /* data-gradient packing (roles of Cin/Cout swapped) */
     int32_t d_CK, d_PS, d_KROWP, d_n_chunk, d_CoutPad;
+    /* stride-2 convs: the data gradient splits by output parity class c = (py, px) into four
+     * stride-1 convs over dy with KH'xKW' taps; tap (r', s') of class c uses the forward tap
+     * (c_R0y - 2 r', c_R0x - 2 s').  Packed like wpk_dgrad, one buffer per class (or NULL). */
+    float *wpk_dcls[4];
+    int32_t c_KH[4], c_KW[4], c_R0y[4], c_R0x[4];
+    int32_t c_CK[4], c_PS[4], c_KROWP[4], c_n_chunk[4], c_CoutPad[4];
 } SisrWeightDesc;
 
 int sisr_weights_prepare(const SisrWeightDesc *table_dev, int32_t n, void *stream);
@@ -202,6 +208,35 @@ int sisr_prelu_slope_grad(const float *dy, const float *pre, int64_t n, float *w
                           void *stream);
 /* y = a + b (same shape) */
 int sisr_add(const float *a, const float *b, float *y, int64_t n, void *stream);
+
+/* ---- layout materialisation ------------------------------------------------------------------
+ * NHWC [N][H][W][C] -> NCHW destination with row stride `dst_stride` floats per image (so a feature
+ * map can be written straight into its slot of a concatenated [B, sum] feature vector), applying
+ * y = lrelu(pa ? pa[c]*x + pd[c] : x, slope).  Used for D's flatten (model_discriminator.py:59),
+ * MaskedVGG's taps (model_content_extractor.py:57-60) and forward_no_end (model_generator.py:86). */
+int sisr_nhwc_to_nchw(const float *x, const float *pa, const float *pd, const float *slope_p,
+                      float slope, float *y, int64_t dst_stride, int32_t N, int32_t H, int32_t W,
+                      int32_t C, void *stream);
+/* inverse gather: NCHW source (row stride src_stride per image) -> NHWC, y = x * (mask_pre ?
+ * (lrelu'(mask_pre)) : 1) is NOT applied here: plain layout change. */
+int sisr_nchw_to_nhwc(const float *x, int64_t src_stride, float *y, int32_t N, int32_t H, int32_t W,
+                      int32_t C, void *stream);
+
+/* ---- fully connected layers of D (nn.Linear, model_discriminator.py:47-53); weight-streaming,
+ *      HBM-bound on W[Nout][K] (75-302 MB).  x operand: lrelu(x, in_slope) applied on load. ------ */
+/* y[b][n] = act( sum_k lrelu(x[b][k]) * W[n][k] + bias[n] ),  epi: 0 none, 1 sigmoid; B <= 16 */
+int sisr_fc_forward(const float *x, float in_slope, const float *W, const float *bias, float *y,
+                    int32_t B, int32_t K, int32_t Nout, int32_t epi, void *stream);
+/* dx[b][k] = sum_n dy[b][n] * W[n][k]; work: [splits][B][K] floats, splits = sisr_fc_dgrad_splits */
+int sisr_fc_dgrad_splits(int32_t K, int32_t Nout);
+int sisr_fc_dgrad(const float *dy, const float *W, float *dx, float *work, int32_t B, int32_t K,
+                  int32_t Nout, void *stream);
+/* dW[n][k] = sum_b dy[b][n] * lrelu(x[b][k], in_slope); db[n] = sum_b dy[b][n] */
+int sisr_fc_wgrad(const float *dy, const float *x, float in_slope, float *dW, float *db, int32_t B,
+                  int32_t K, int32_t Nout, void *stream);
+/* elementwise helpers for the tiny FC activations: dy_pre = dy * act'(...) */
+int sisr_act_bwd(const float *dy, const float *ref, float *out, int64_t n, int32_t kind, float slope,
+                 void *stream);   /* kind 0: leaky (ref = pre-activation), 1: sigmoid (ref = output) */
 
 /* ---- bicubic degradation, align_corners=True, A=-0.75, clamp to [-1,1]
  *      (utils.py:16-31: F.interpolate(..., 'bicubic', align_corners=True) + _crop_lr) -------- */

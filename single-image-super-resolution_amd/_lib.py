@@ -57,7 +57,10 @@ class WeightDesc(C.Structure):
     _fields_ = ([(n, _f) for n in ('w_orig', 'u', 'v', 'u_used', 'v_used', 'sigma', 'wpk_fwd', 'wpk_dgrad')] +
                 [(n, _i32) for n in ('Cout', 'Cin', 'KH', 'KW', 'training', 'shuffle2',
                                      'f_CK', 'f_PS', 'f_KROWP', 'f_n_chunk', 'f_CoutPad',
-                                     'd_CK', 'd_PS', 'd_KROWP', 'd_n_chunk', 'd_CoutPad')])
+                                     'd_CK', 'd_PS', 'd_KROWP', 'd_n_chunk', 'd_CoutPad')] +
+                [('wpk_dcls', _f * 4)] +
+                [(n, _i32 * 4) for n in ('c_KH', 'c_KW', 'c_R0y', 'c_R0x', 'c_CK', 'c_PS', 'c_KROWP',
+                                         'c_n_chunk', 'c_CoutPad')])
 
 
 class WeightGradDesc(C.Structure):
@@ -89,6 +92,13 @@ _SIGS = {
     'sisr_eltwise_res_affine': [_f, _f, _f32, _f, _f, _f, _f, _i64, _i32, _f],
     'sisr_prelu_slope_grad': [_f, _f, _i64, _f, _f, _f],
     'sisr_add': [_f, _f, _f, _i64, _f],
+    'sisr_nhwc_to_nchw': [_f, _f, _f, _f, _f32, _f, _i64, _i32, _i32, _i32, _i32, _f],
+    'sisr_nchw_to_nhwc': [_f, _i64, _f, _i32, _i32, _i32, _i32, _f],
+    'sisr_fc_forward': [_f, _f32, _f, _f, _f, _i32, _i32, _i32, _i32, _f],
+    'sisr_fc_dgrad_splits': [_i32, _i32],
+    'sisr_fc_dgrad': [_f, _f, _f, _f, _i32, _i32, _i32, _f],
+    'sisr_fc_wgrad': [_f, _f, _f32, _f, _f, _i32, _i32, _i32, _f],
+    'sisr_act_bwd': [_f, _f, _f, _i64, _i32, _f32, _f],
     'sisr_bicubic_fwd': [_f, _f, _i32, _i32, _i32, _i32, _i32, _i32, _f],
     'sisr_bicubic_bwd': [_f, _f, _f, _i32, _i32, _i32, _i32, _i32, _f],
     'sisr_struct_sizes': [C.POINTER(_i32), _i32],

@@ -125,6 +125,28 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
             w.wpk_dgrad[e] = val;
         }
     }
+    // stride-2 data gradient: one packed image per output parity class
+    for (int cls = 0; cls < 4; ++cls) {
+        float* dst = w.wpk_dcls[cls];
+        if (dst == nullptr) continue;
+        const int KHc = w.c_KH[cls], KWc = w.c_KW[cls];
+        const int CK = w.c_CK[cls], PS = w.c_PS[cls], KROWP = w.c_KROWP[cls], CoutPad = w.c_CoutPad[cls];
+        const int64_t total = (int64_t)w.c_n_chunk[cls] * KHc * CoutPad * KROWP;
+        for (int64_t e = start; e < total; e += stride) {
+            int64_t tq = e;
+            const int krow = (int)(tq % KROWP); tq /= KROWP;
+            const int op = (int)(tq % CoutPad); tq /= CoutPad;
+            const int rp = (int)(tq % KHc);
+            const int chunk = (int)(tq / KHc);
+            const int sp = krow / PS, il = krow - sp * PS;
+            const int ip = chunk * CK + il;
+            const int r = w.c_R0y[cls] - 2 * rp, sx = w.c_R0x[cls] - 2 * sp;
+            float val = 0.f;
+            if (sp < KWc && il < CK && ip < w.Cout && op < w.Cin && r >= 0 && r < w.KH && sx >= 0 && sx < w.KW)
+                val = w.w_orig[(((int64_t)ip * w.Cin + op) * w.KH + r) * w.KW + sx] * inv;
+            dst[e] = val;
+        }
+    }
 }
 
 // weight-gradient epilogue: one workgroup per weight

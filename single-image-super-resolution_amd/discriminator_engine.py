@@ -1,0 +1,142 @@
+"""Hand-scheduled forward / backward of the SRGAN discriminator (SURVEY row a5;
+model_discriminator.py:18-62) on the gfx950 kernels:
+
+    SN-conv(3->f0) -> LeakyReLU -> k x [SN-conv(stride 1|2) -> BN -> LeakyReLU] -> flatten (NCHW order)
+    -> Linear(fc_in, 2*f_last) -> LeakyReLU -> Linear(., 1) -> Sigmoid
+
+Every conv consumes its producer lazily (BatchNorm-apply + LeakyReLU folded into tile staging) and
+emits its own BatchNorm statistics, so no normalisation/activation pass touches HBM; the only
+materialisation is the final 16 x fc_in flatten.  The data gradient of the stride-2 convs runs as
+four output-parity classes (stride-1 convs with 1/2/2/4 taps) -- no zero-stuffed work.  The FC
+layers stream their 75-302 MB weight exactly once per pass.
+"""
+import torch
+
+from . import _lib as L
+from . import engine as E
+from .engine import Operand
+
+LEAKY = 0.01          # nn.LeakyReLU() default, model_discriminator.py:12,40,50
+
+
+class Topology:
+    def __init__(self):
+        self.conv0 = None        # ConvRef
+        self.blocks = []         # (ConvRef, bn module)
+        self.fc1 = None          # nn.Linear holders
+        self.fc2 = None
+
+    def conv_refs(self):
+        return [self.conv0] + [b[0] for b in self.blocks]
+
+
+class Saved:
+    pass
+
+
+def run_forward(topo, x, training):
+    E.require_gpu_tensor(x, 'discriminator input')
+    x = x.contiguous()
+    n, cimg, h, w = x.shape
+    if n > 16:
+        raise NotImplementedError('the FC kernels keep the batch in registers: batch <= 16 (reference uses 16)')
+    refs = topo.conv_refs()
+    items, hh, ww = [], h, w
+    for ref in refs:
+        items.append((ref, n, hh, ww))
+        hh, ww = ref.geom.out_hw(hh, ww)
+    preps, keep = E.prepare_weights(items, training)
+    P = {id(r): p for r, p in zip(refs, preps)}
+    sv = Saved()
+    sv.topo, sv.P, sv.keep, sv.x, sv.training = topo, P, keep, x, training
+    x_op = Operand.plain(x, dims=(n, h, w, cimg), mode=L.X_NCHW)
+    c0, _, _ = E.conv_forward(P[id(topo.conv0)], x_op, bias=topo.conv0.bias)
+    sv.c0 = c0
+    cur = Operand.act(c0, LEAKY)
+    sv.ins, sv.cs, sv.ks = [], [], []
+    for ref, bn in topo.blocks:
+        sv.ins.append(cur)
+        o = E.conv_forward(P[id(ref)], cur, bias=ref.bias, stats=training)
+        k = E.bn_finalize(o[1], o[2], bn) if training else E.bn_eval_consts(bn)
+        sv.cs.append(o[0])
+        sv.ks.append(k)
+        cur = Operand.affine_act(o[0], k[0], k[1], LEAKY)
+    last = cur.x1
+    fc_in = last.shape[1] * last.shape[2] * last.shape[3]
+    flat = torch.empty((n, fc_in), dtype=torch.float32, device=x.device)
+    E.nhwc_to_nchw(last, flat, fc_in, cur.pa, cur.pd, LEAKY)            # x.view(B, fc_in) of NCHW
+    sv.flat, sv.last_shape = flat, tuple(last.shape)
+    sv.h1 = E.fc_forward(flat, topo.fc1.weight, topo.fc1.bias)           # pre-activation
+    sv.out = E.fc_forward(sv.h1, topo.fc2.weight, topo.fc2.bias, in_slope=LEAKY, sigmoid=True)
+    if training and topo.blocks:
+        torch._foreach_add_([bn.num_batches_tracked for _, bn in topo.blocks], 1)
+    return sv.out, sv
+
+
+def run_backward(sv, grad_out, need_dx):
+    if not sv.training:
+        raise NotImplementedError('backward through an eval-mode discriminator forward is not implemented')
+    topo, P = sv.topo, sv.P
+    grads = {}
+    wg = E.WeightGradBatch()
+    grad_out = grad_out.contiguous()
+    n = sv.x.shape[0]
+    d2 = E.act_bwd(grad_out, sv.out, 1)                                   # sigmoid'
+    dx2, dw2, db2 = E.fc_backward(d2, sv.h1, topo.fc2.weight, in_slope=LEAKY)
+    grads[id(topo.fc2.weight)], grads[id(topo.fc2.bias)] = dw2, db2
+    d1 = E.act_bwd(dx2, sv.h1, 0, LEAKY)                                  # LeakyReLU'
+    dflat, dw1, db1 = E.fc_backward(d1, sv.flat, topo.fc1.weight)
+    grads[id(topo.fc1.weight)], grads[id(topo.fc1.bias)] = dw1, db1
+    _, hl, wl, cl = sv.last_shape
+    g = E.nchw_to_nhwc(dflat, dflat.shape[1], n, hl, wl, cl)              # grad wrt activated last map
+
+    def conv_bwd(ref, x_op, dy_op, need_dgrad=True, y_mode=L.Y_NHWC):
+        p = P[id(ref)]
+        want_w, want_b = ref.weight.requires_grad, ref.bias is not None and ref.bias.requires_grad
+        if want_w or want_b:
+            wg.add(p, E.conv_wgrad(p, x_op, dy_op), want_w, want_b)
+        return E.conv_dgrad(p, dy_op, y_mode=y_mode) if need_dgrad else None
+
+    for i in range(len(topo.blocks) - 1, -1, -1):
+        ref, bn = topo.blocks[i]
+        c, k = sv.cs[i], sv.ks[i]
+        q, dgam, dbet, _ = E.bn_backward(g, c, k, bn.weight, slope=LEAKY)
+        grads[id(bn.weight)], grads[id(bn.bias)] = dgam, dbet
+        dy = Operand(g, tuple(c.shape), pro=L.PRO_BNACT_BWD, x2=c, pa=q[0], pb=q[1], pd=q[2], ps=k[0], pt=k[1],
+                     slope=LEAKY)
+        g = conv_bwd(ref, sv.ins[i], dy)
+    dy0 = Operand(g, tuple(sv.c0.shape), pro=L.PRO_ACT_BWD, x2=sv.c0, slope=LEAKY)
+    x_op = Operand.plain(sv.x, dims=(n, sv.x.shape[2], sv.x.shape[3], sv.x.shape[1]), mode=L.X_NCHW)
+    if need_dx and topo.conv0.geom.stride != 1:
+        raise NotImplementedError('input gradient through a stride-2 first convolution')
+    gx = conv_bwd(topo.conv0, x_op, dy0, need_dgrad=need_dx, y_mode=L.Y_NCHW)
+    refs = topo.conv_refs()
+    for ref_id, (gw, gb) in wg.run().items():
+        ref = next(r for r in refs if id(r) == ref_id)
+        if gw is not None:
+            grads[id(ref.weight)] = gw
+        if gb is not None:
+            grads[id(ref.bias)] = gb
+    return grads, gx
+
+
+class DiscriminatorFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, topo, training, x, *params):
+        out, sv = run_forward(topo, x, training)
+        ctx.sv, ctx.params = sv, params
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grads, gx = run_backward(ctx.sv, grad_out, ctx.needs_input_grad[2])
+        ctx.sv = None
+        return (None, None, gx) + tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
+
+
+def discriminator_apply(topo, module, x):
+    params = list(module.parameters())
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+        return DiscriminatorFunction.apply(topo, module.training, x, *params)
+    out, _ = run_forward(topo, x, module.training)
+    return out

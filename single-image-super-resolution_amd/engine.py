@@ -81,6 +81,20 @@ class ConvGeom:
     def out_hw(self, h, w):
         return ((h + 2 * self.pad - self.k) // self.stride + 1, (w + 2 * self.pad - self.k) // self.stride + 1)
 
+    def _s2_class_plan(self, lib, n, h, w, ho, wo, py, px):
+        khc, pady, r0y = _s2_taps(self.k, self.pad, py)
+        kwc, padx, r0x = _s2_taps(self.k, self.pad, px)
+        hc, wc = (h - py + 1) // 2, (w - px + 1) // 2
+        if khc == 0 or kwc == 0 or hc <= 0 or wc <= 0:
+            return None
+        d = L.ConvDesc()
+        d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, ho, wo, self.cout, hc, wc, self.cin
+        d.KH, d.KW, d.stride, d.pad_y, d.pad_x = khc, kwc, 1, pady, padx
+        d.y_sy = d.y_sx = 2
+        d.y_oy, d.y_ox, d.y_H, d.y_W = py, px, h, w
+        L.check(lib.sisr_conv2d_plan(C.byref(d)), 'sisr_conv2d_plan(dgrad stride-2 class)')
+        return (d, r0y, r0x)
+
     def plans(self, n, h, w, max_pixel_blocks=512):
         key = (n, h, w)
         if key in self._plans:
@@ -106,6 +120,8 @@ class ConvGeom:
             d.y_sy = d.y_sx = 1
             d.y_H, d.y_W = h, w
             L.check(lib.sisr_conv2d_plan(C.byref(d)), 'sisr_conv2d_plan(dgrad)')
+        else:
+            d = [self._s2_class_plan(lib, n, h, w, ho, wo, py, px) for py in (0, 1) for px in (0, 1)]
         g = L.WgradDesc()
         g.N, g.H, g.W, g.Cin, g.Ho, g.Wo, g.Cout = n, h, w, self.cin, ho, wo, self.cout
         g.KH = g.KW = self.k
@@ -114,6 +130,15 @@ class ConvGeom:
         g.slab_stride = g.slab_elems + g.CoutPad
         self._plans[key] = (f, d, g)
         return self._plans[key]
+
+
+def _s2_taps(k, pad, parity):
+    """stride-2 data gradient along one axis, output index 2a+parity: contributing dy index a+delta
+    for forward taps r with (parity+pad-r) even.  -> (n_taps, pad', R0) with r = R0 - 2 r'."""
+    deltas = sorted((parity + pad - r) // 2 for r in range(k) if (parity + pad - r) % 2 == 0)
+    if not deltas:
+        return 0, 0, 0
+    return len(deltas), -deltas[0], parity + pad - 2 * deltas[0]
 
 
 class ConvRef:
@@ -140,7 +165,13 @@ def prepare_weights(items, training, need_dgrad=True):
         off_f = total
         total += _align4(f.plan.wpk_elems)
         off_d = None
-        if need_dgrad and d is not None:
+        if need_dgrad and isinstance(d, list):
+            off_d = []
+            for cls in d:
+                off_d.append(None if cls is None else total)
+                if cls is not None:
+                    total += _align4(cls[0].plan.wpk_elems)
+        elif need_dgrad and d is not None:
             off_d = total
             total += _align4(d.plan.wpk_elems)
         off_s = small
@@ -156,18 +187,30 @@ def prepare_weights(items, training, need_dgrad=True):
         p = Prepared()
         p.ref, p.plans = ref, (f, d, g)
         p.wpk_fwd = big[off_f:off_f + f.plan.wpk_elems]
-        p.wpk_dgrad = big[off_d:off_d + d.plan.wpk_elems] if off_d is not None else None
+        if isinstance(off_d, list):
+            p.wpk_dgrad = [None if o is None else big[o:o + cls[0].plan.wpk_elems] for o, cls in zip(off_d, d)]
+        else:
+            p.wpk_dgrad = big[off_d:off_d + d.plan.wpk_elems] if off_d is not None else None
         p.sigma = sm[off_s:off_s + 1]
         t = table[i]
         t.w_orig = ref.weight.data_ptr()
         t.sigma = p.sigma.data_ptr()
         t.wpk_fwd = p.wpk_fwd.data_ptr()
-        t.wpk_dgrad = _ptr(p.wpk_dgrad)
+        t.wpk_dgrad = None if isinstance(p.wpk_dgrad, list) else _ptr(p.wpk_dgrad)
         t.Cout, t.Cin, t.KH, t.KW = gm.cout, gm.cin, gm.k, gm.k
         t.training, t.shuffle2 = int(training), int(gm.shuffle2)
         t.f_CK, t.f_PS, t.f_KROWP, t.f_n_chunk, t.f_CoutPad = (f.plan.CK, f.plan.PS, f.plan.KROWP,
                                                                  f.plan.n_chunk, f.plan.CoutPad)
-        if off_d is not None:
+        if isinstance(off_d, list):
+            for ci, (cls, buf) in enumerate(zip(d, p.wpk_dgrad)):
+                if cls is None:
+                    continue
+                cd, r0y, r0x = cls
+                t.wpk_dcls[ci] = buf.data_ptr()
+                t.c_KH[ci], t.c_KW[ci], t.c_R0y[ci], t.c_R0x[ci] = cd.KH, cd.KW, r0y, r0x
+                t.c_CK[ci], t.c_PS[ci], t.c_KROWP[ci] = cd.plan.CK, cd.plan.PS, cd.plan.KROWP
+                t.c_n_chunk[ci], t.c_CoutPad[ci] = cd.plan.n_chunk, cd.plan.CoutPad
+        elif off_d is not None:
             t.d_CK, t.d_PS, t.d_KROWP, t.d_n_chunk, t.d_CoutPad = (d.plan.CK, d.plan.PS, d.plan.KROWP,
                                                                      d.plan.n_chunk, d.plan.CoutPad)
         p.u_used = p.v_used = None
@@ -222,8 +265,23 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
 def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC):
     """Data gradient: conv over the (lazy) output gradient with the flipped packed weights."""
     lib = L.lib()
-    d = _copy_struct(prep.plans[1])
     gm = prep.ref.geom
+    if isinstance(prep.plans[1], list):          # stride 2: four output-parity classes
+        f = prep.plans[0]
+        dev = dy_op.x1.device
+        assert y_mode == L.Y_NHWC
+        complete = all(c is not None for c in prep.plans[1])
+        out = (torch.empty if complete else torch.zeros)((f.N, f.H, f.W, gm.cin), dtype=torch.float32, device=dev)
+        for cls, buf in zip(prep.plans[1], prep.wpk_dgrad):
+            if cls is None:
+                continue
+            d = _copy_struct(cls[0])
+            assert tuple(dy_op.dims) == (d.N, d.H, d.W, d.Cin), (dy_op.dims, (d.N, d.H, d.W, d.Cin))
+            dy_op.fill(d)
+            d.wpk, d.bias, d.res, d.y = buf.data_ptr(), None, _ptr(res), out.data_ptr()
+            L.check(lib.sisr_conv2d_f32(C.byref(d), _stream()), 'sisr_conv2d_f32(dgrad s2)')
+        return out
+    d = _copy_struct(prep.plans[1])
     assert tuple(dy_op.dims) == (d.N, d.H, d.W, d.Cin), (dy_op.dims, (d.N, d.H, d.W, d.Cin))
     dev = dy_op.x1.device
     d.y_mode = y_mode
@@ -378,3 +436,52 @@ def require_gpu_tensor(x, what):
                            'CPU fallback' % (what, getattr(x, 'device', type(x))))
     if x.dtype != torch.float32:
         raise RuntimeError('%s: fp32 tensors expected, got %s' % (what, x.dtype))
+
+
+def nhwc_to_nchw(x, out, dst_stride, pa=None, pd=None, slope=None):
+    """materialise lrelu(pa*x+pd, slope) from NHWC x into an NCHW destination (rows of `out`)."""
+    n, h, w, c = x.shape
+    sp, sv = (slope.data_ptr(), 1.0) if isinstance(slope, torch.Tensor) else (None, 1.0 if slope is None else float(slope))
+    L.check(L.lib().sisr_nhwc_to_nchw(x.data_ptr(), _ptr(pa), _ptr(pd), sp, sv, out.data_ptr(), dst_stride,
+                                      n, h, w, c, _stream()), 'sisr_nhwc_to_nchw')
+
+
+def nchw_to_nhwc(src, src_stride, n, h, w, c):
+    y = torch.empty((n, h, w, c), dtype=torch.float32, device=src.device)
+    L.check(L.lib().sisr_nchw_to_nhwc(src.data_ptr(), src_stride, y.data_ptr(), n, h, w, c, _stream()),
+            'sisr_nchw_to_nhwc')
+    return y
+
+
+def fc_forward(x, w, b, in_slope=1.0, sigmoid=False):
+    bsz, k = x.shape
+    y = torch.empty((bsz, w.shape[0]), dtype=torch.float32, device=x.device)
+    L.check(L.lib().sisr_fc_forward(x.data_ptr(), in_slope, w.data_ptr(), _ptr(b), y.data_ptr(), bsz, k,
+                                    w.shape[0], int(sigmoid), _stream()), 'sisr_fc_forward')
+    return y
+
+
+def fc_backward(dy, x, w, in_slope=1.0, need_dx=True):
+    """-> (dx wrt lrelu(x) [B,K] or None, dW, db)"""
+    lib = L.lib()
+    bsz, k = x.shape
+    nout = w.shape[0]
+    dw = torch.empty_like(w)
+    db = torch.empty((nout,), dtype=torch.float32, device=x.device)
+    L.check(lib.sisr_fc_wgrad(dy.data_ptr(), x.data_ptr(), in_slope, dw.data_ptr(), db.data_ptr(), bsz, k, nout,
+                              _stream()), 'sisr_fc_wgrad')
+    dx = None
+    if need_dx:
+        splits = lib.sisr_fc_dgrad_splits(k, nout)
+        work = torch.empty((splits, bsz, k), dtype=torch.float32, device=x.device)
+        dx = torch.empty((bsz, k), dtype=torch.float32, device=x.device)
+        L.check(lib.sisr_fc_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), work.data_ptr(), bsz, k, nout,
+                                  _stream()), 'sisr_fc_dgrad')
+    return dx, dw, db
+
+
+def act_bwd(dy, ref, kind, slope=0.0):
+    out = torch.empty_like(dy)
+    L.check(L.lib().sisr_act_bwd(dy.data_ptr(), ref.data_ptr(), out.data_ptr(), dy.numel(), kind, slope,
+                                 _stream()), 'sisr_act_bwd')
+    return out
