@@ -222,6 +222,19 @@ int sisr_nhwc_to_nchw(const float *x, const float *pa, const float *pd, const fl
 int sisr_nchw_to_nhwc(const float *x, int64_t src_stride, float *y, int32_t N, int32_t H, int32_t W,
                       int32_t C, void *stream);
 
+/* ---- MaxPool2d(2,2) of the VGG19 stack (model_content_extractor.py:43; floors odd sizes), NHWC.
+ * Pooling commutes with the (monotonic) ReLU in front of it, so the forward pools the RAW conv
+ * output and the consumer applies ReLU lazily; the backward fuses MaxPool' and ReLU':
+ *   dx[argmax of the 2x2 window] = (x[argmax] > 0) ? dy : 0, all other positions 0
+ * (first maximum in row-major window order, like ATen). */
+int sisr_maxpool2_fwd(const float *x, float *y, int32_t N, int32_t H, int32_t W, int32_t C, void *stream);
+int sisr_maxpool2_relu_bwd(const float *dy, const float *x, float *dx, int32_t N, int32_t H, int32_t W,
+                           int32_t C, void *stream);
+/* out = a + (ref > 0 ? b : 0)   (a may be NULL: out = masked b) -- merges a tap gradient into the
+ * gradient of the ReLU it was taken behind (MaskedVGG's in-place-ReLU aliasing). */
+int sisr_add_relu_masked(const float *a, const float *b, const float *ref, float *out, int64_t n,
+                         void *stream);
+
 /* ---- fully connected layers of D (nn.Linear, model_discriminator.py:47-53); weight-streaming,
  *      HBM-bound on W[Nout][K] (75-302 MB).  x operand: lrelu(x, in_slope) applied on load. ------ */
 /* y[b][n] = act( sum_k lrelu(x[b][k]) * W[n][k] + bias[n] ),  epi: 0 none, 1 sigmoid; B <= 16 */

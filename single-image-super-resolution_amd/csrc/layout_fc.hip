@@ -194,7 +194,112 @@ __global__ void fc_split_reduce_kernel(const float* __restrict__ work, float* __
     }
 }
 
+// ---- MaxPool2d(2,2) + fused ReLU backward (VGG19 features), NHWC float4 along C -------------------
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C4,
+                                    int Ho, int Wo, int64_t total) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        int64_t t = e / C4;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const f32x4* p = reinterpret_cast<const f32x4*>(x) + (((int64_t)n * H + 2 * oy) * W + 2 * ox) * C4 + c4;
+        const f32x4 a = p[0], b = p[C4], c = p[(int64_t)W * C4], d = p[(int64_t)W * C4 + C4];
+        f32x4 m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(c[j], d[j]));
+        reinterpret_cast<f32x4*>(y)[e] = m;
+    }
+}
+
+__global__ void maxpool2_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                         float* __restrict__ dx, int H, int W, int C4, int Ho, int Wo,
+                                         int64_t total) {
+    // one thread per (pooled pixel, channel group): writes its whole 2x2 window of dx
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        int64_t t = e / C4;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const int64_t base = (((int64_t)n * H + 2 * oy) * W + 2 * ox) * C4 + c4;
+        const int64_t offs[4] = {0, C4, (int64_t)W * C4, (int64_t)W * C4 + C4};
+        const f32x4* p = reinterpret_cast<const f32x4*>(x) + base;
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = p[offs[k]];
+        const f32x4 g = reinterpret_cast<const f32x4*>(dy)[e];
+        f32x4 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int am = 0;
+            float mv = v[0][j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (v[k][j] > mv) { mv = v[k][j]; am = k; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k][j] = (k == am && mv > 0.f) ? g[j] : 0.f;
+        }
+        f32x4* q = reinterpret_cast<f32x4*>(dx) + base;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[offs[k]] = o[k];
+    }
+}
+
+// odd H/W: the last row / column is not covered by any window -> zero gradient
+__global__ void maxpool2_bwd_edge_kernel(float* __restrict__ dx, int N, int H, int W, int C) {
+    const int64_t total = (int64_t)N * H * W * C;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = e / C;
+        const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
+        if (((H & 1) && yh == H - 1) || ((W & 1) && xw == W - 1)) dx[e] = 0.f;
+    }
+}
+
+__global__ void add_relu_masked_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                       const float* __restrict__ ref, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float m = ref[i] > 0.f ? b[i] : 0.f;
+        out[i] = (a != nullptr ? a[i] : 0.f) + m;
+    }
+}
+
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" int sisr_maxpool2_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    if (!x || !y || N <= 0 || H < 2 || W < 2 || C <= 0 || (C & 3)) return SISR_E_BADARG;
+    const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const int64_t total = (int64_t)N * Ho * Wo * C4;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(blocks), dim3(256), 0, S_(stream), x, y, H, W, C4, Ho, Wo, total);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_maxpool2_relu_bwd(const float* dy, const float* x, float* dx, int32_t N, int32_t H, int32_t W,
+                                      int32_t C, void* stream) {
+    if (!dy || !x || !dx || N <= 0 || H < 2 || W < 2 || C <= 0 || (C & 3)) return SISR_E_BADARG;
+    const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const int64_t total = (int64_t)N * Ho * Wo * C4;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(maxpool2_relu_bwd_kernel, dim3(blocks), dim3(256), 0, S_(stream), dy, x, dx, H, W, C4, Ho, Wo,
+                       total);
+    SISR_CHECK_LAUNCH();
+    if ((H & 1) || (W & 1)) {
+        hipLaunchKernelGGL(maxpool2_bwd_edge_kernel, dim3(1024), dim3(256), 0, S_(stream), dx, N, H, W, C);
+        SISR_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int sisr_add_relu_masked(const float* a, const float* b, const float* ref, float* out, int64_t n,
+                                    void* stream) {
+    if (!b || !ref || !out || n <= 0) return SISR_E_BADARG;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(add_relu_masked_kernel, dim3(blocks), dim3(256), 0, S_(stream), a, b, ref, out, n);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int sisr_nhwc_to_nchw(const float* x, const float* pa, const float* pd, const float* slope_p,
                                  float slope, float* y, int64_t dst_stride, int32_t N, int32_t H, int32_t W,

@@ -485,3 +485,25 @@ def act_bwd(dy, ref, kind, slope=0.0):
     L.check(L.lib().sisr_act_bwd(dy.data_ptr(), ref.data_ptr(), out.data_ptr(), dy.numel(), kind, slope,
                                  _stream()), 'sisr_act_bwd')
     return out
+
+
+def maxpool2(x):
+    n, h, w, c = x.shape
+    y = torch.empty((n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+    L.check(L.lib().sisr_maxpool2_fwd(x.data_ptr(), y.data_ptr(), n, h, w, c, _stream()), 'sisr_maxpool2_fwd')
+    return y
+
+
+def maxpool2_relu_bwd(dy, x):
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    L.check(L.lib().sisr_maxpool2_relu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), n, h, w, c, _stream()),
+            'sisr_maxpool2_relu_bwd')
+    return dx
+
+
+def add_relu_masked(a, b, ref):
+    out = torch.empty_like(b)
+    L.check(L.lib().sisr_add_relu_masked(_ptr(a), b.data_ptr(), ref.data_ptr(), out.data_ptr(), b.numel(),
+                                         _stream()), 'sisr_add_relu_masked')
+    return out

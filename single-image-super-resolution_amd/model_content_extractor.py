@@ -1,0 +1,94 @@
+"""Drop-in for the reference's ``model_content_extractor`` module
+(model_content_extractor.py:1-73): ``identity()``, ``MaskedVGG(mask)``, ``get_size`` and the module
+constants, with ``MaskedVGG.forward`` on the gfx950 kernels (vgg_engine.py).
+
+Weights: the reference builds ``torchvision.models.vgg19(pretrained=True).features[:k]``
+(model_content_extractor.py:43), a remote fetch.  If torchvision and its weights are available they
+are loaded; otherwise (no network / no torchvision) the stack is initialised with torch's default
+Conv2d init under a fixed seed and a warning is printed -- load real weights with
+``load_state_dict`` (keys ``layers.<features index>.weight|bias``, as in the reference).
+"""
+import warnings
+
+import torch
+import torch.nn as nn
+
+from . import vgg_engine as VE
+from .layers import Conv2d, ConvRef, Marker
+
+# indices of the MaxPool layers in VGG19.features (the last one is never used)
+maxPool_indexes = (4, 9, 18, 27, 36)
+maxPool_indexes_before_act = [x - 1 for x in maxPool_indexes]
+# feature-map widths (for tests)
+layersSize = (64, 128, 256, 512, 512)
+
+_VGG19_CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M')
+
+
+def identity():
+    """plain pixel MSE (model_content_extractor.py:12-14)"""
+    return nn.Identity()
+
+
+def _vgg19_feature_modules(n_layers, width_div=1):
+    mods, cin = [], 3
+    for v in _VGG19_CFG:
+        if v == 'M':
+            mods.append(Marker('MaxPool2d(2,2)'))
+        else:
+            mods.append(Conv2d(cin, v // width_div, 3, 1, 1))
+            mods.append(Marker('ReLU'))
+            cin = v // width_div
+    return mods[:n_layers]
+
+
+class MaskedVGG(nn.Module):
+    """concatenates the VGG19 feature maps taken right before the MaxPools whose mask bit is set;
+    output shape (B, -1) (model_content_extractor.py:33-60)."""
+
+    def __init__(self, mask, width_div=1, pretrained=True):
+        super().__init__()
+        assert 0 < mask < 32
+        self.intermediate_layers_kept = [maxPool_indexes_before_act[i] for i in range(5) if mask & (1 << i)]
+        gen_state = torch.random.get_rng_state()
+        torch.manual_seed(1234)
+        self.layers = nn.Sequential(*_vgg19_feature_modules(self.intermediate_layers_kept[-1], width_div))
+        torch.random.set_rng_state(gen_state)
+        if pretrained and width_div == 1:
+            self._try_load_torchvision()
+        self.layers.eval()
+        self.layers.requires_grad = False
+        for param in self.layers.parameters():
+            param.requires_grad = False
+        convs, pool_pending = [], False
+        for i, m in enumerate(self.layers, 1):
+            if isinstance(m, Conv2d):
+                tap = self.intermediate_layers_kept.index(i) if i in self.intermediate_layers_kept else None
+                convs.append(dict(ref=ConvRef(m), pool_before=pool_pending, tap=tap))
+                pool_pending = False
+            elif m.what.startswith('MaxPool'):
+                pool_pending = True
+        self._prog = VE.Program(convs, len(self.intermediate_layers_kept))
+
+    def _try_load_torchvision(self):
+        try:
+            import torchvision.models as models
+            feats = models.vgg19(pretrained=True).features[:self.intermediate_layers_kept[-1]]
+            self.layers.load_state_dict(feats.state_dict(), strict=True)
+        except Exception as e:                                  # noqa: BLE001
+            warnings.warn('MaskedVGG: pretrained VGG19 weights unavailable (%s: %s); using a seeded default '
+                          'initialisation -- load real weights with load_state_dict' % (type(e).__name__, e))
+
+    def forward(self, x):
+        return VE.vgg_apply(self._prog, x)
+
+
+def get_size(im, mask):
+    """model_content_extractor.py:63-73"""
+    assert im.shape[1] == 3
+    w, h = im.shape[2], im.shape[3]
+    size = 0
+    for i in range(len(layersSize)):
+        if mask & (1 << i):
+            size += (w // 2 ** i) * (h // 2 ** i) * layersSize[i]
+    return size
