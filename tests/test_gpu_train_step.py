@@ -1,0 +1,90 @@
+"""GPU: the loss graph of one training iteration (row a7), sequenced exactly like the reference's
+train_loop (train.py:45-108) with an empty replay list: D step (D(real), D(fake.detach()), BCE with
+labels 0.9 / 0), then G step (D(fake) with label 1 weighted 5e-2 + VGG feature MSE), using the
+drop-in modules; compared with the same sequence on the CPU oracle, including the spectral-norm /
+BatchNorm state that advances between the three D forwards."""
+import pytest
+import torch
+
+from gpu_helpers import pkg
+from helpers import grads_close, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+FEATS, STRIDES = [16, 16, 32, 32], [1, 2, 1, 2]
+
+
+def _oracle_iteration(g_state, d_state, v_state, hr, mask, lr_size):
+    from oracle import models as om, ops as oo, losses as ol
+    g_state = {k: v.clone() for k, v in g_state.items()}
+    d_state = {k: v.clone() for k, v in d_state.items()}
+    for st in (g_state, d_state):
+        for k in om.param_keys(st):
+            st[k].requires_grad_(True)
+    img_lr = oo.lr_from_hr(hr, lr_size)                                           # train.py:46
+    fake, g_new = om.generator_forward(g_state, img_lr, (2,), True, 0)            # train.py:53
+    # ---- D step (train.py:58-75, 128-168)
+    d_real, new = om.discriminator_forward(d_state, hr, STRIDES, True)
+    d_state.update(new)
+    d_fake, new = om.discriminator_forward(d_state, fake.detach(), STRIDES, True)
+    d_state.update(new)
+    err_d = ol.adversarial_loss_d(d_real, [d_fake]) * ol.W_ADV_D
+    err_d.backward()
+    d_grads = {k: d_state[k].grad.clone() for k in om.param_keys(d_state)}
+    # ---- G step (train.py:82-108, 171-186)
+    d_out, new = om.discriminator_forward(d_state, fake, STRIDES, True)
+    d_state.update(new)
+    err_adv = ol.adversarial_loss_g(d_out) * ol.W_ADV_G
+    with torch.no_grad():
+        f_real = om.masked_vgg_forward(v_state, hr, mask)
+    f_fake = om.masked_vgg_forward(v_state, fake, mask)
+    err_cont = ol.content_loss_g(f_real, f_fake) * ol.W_CONTENT
+    (err_adv + err_cont).backward()
+    g_grads = {k: g_state[k].grad for k in om.param_keys(g_state)}
+    d_buffers = {k: v for k, v in d_state.items() if k.endswith(('weight_u', 'running_mean', 'running_var'))}
+    return err_d.detach(), err_adv.detach(), err_cont.detach(), d_grads, g_grads, d_buffers
+
+
+def test_one_training_iteration_matches_oracle():
+    mg, md, mce, ut = pkg('model_generator'), pkg('model_discriminator'), pkg('model_content_extractor'), pkg('utils')
+    torch.manual_seed(0)
+    net_g = mg.Generator(2, 16, 64, [2], use_sn=True)
+    net_d = md.Discriminator((3, 32, 32), FEATS, STRIDES)
+    mask = 0b00011
+    ext = mce.MaskedVGG(mask, width_div=4, pretrained=False)
+    g_state = {k: v.detach().clone() for k, v in net_g.state_dict().items()}
+    d_state = {k: v.detach().clone() for k, v in net_d.state_dict().items()}
+    v_state = {k: v.detach().clone() for k, v in ext.state_dict().items()}
+    hr = torch.rand(8, 3, 32, 32, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    ref = _oracle_iteration(g_state, d_state, v_state, hr, mask, (16, 16))
+
+    dev = torch.device('cuda')
+    net_g, net_d, ext = net_g.to(dev), net_d.to(dev), ext.to(dev)
+    criterion = torch.nn.BCELoss()                                                # config.py:107
+    bs = hr.shape[0]
+    real_label = torch.full((bs,), 1.0, device=dev)
+    real_label_reduced = torch.full((bs,), .9, device=dev)
+    fake_label = torch.full((bs,), .0, device=dev)
+    img_hr = hr.to(dev)
+    img_lr = ut.lr_from_hr(img_hr, (16, 16), device=dev)
+    fake = net_g(img_lr)
+    net_d.zero_grad()
+    err_d = criterion(net_d(img_hr).view(-1), real_label_reduced) + criterion(net_d(fake.detach()).view(-1), fake_label)
+    err_d = err_d * 1.0
+    err_d.backward()
+    d_grads = {k: p.grad.detach().cpu().clone() for k, p in net_d.named_parameters()}
+    net_g.zero_grad()
+    err_adv = criterion(net_d(fake).view(-1), real_label) * 5e-2
+    a, b = ext(img_hr), ext(fake)
+    err_cont = torch.mean(torch.pow(a - b, 2)) * 1.0
+    (err_adv + err_cont).backward()
+    g_grads = {k: p.grad.detach().cpu() for k, p in net_g.named_parameters()}
+
+    assert abs(float(err_d) - float(ref[0])) < TOL * max(1.0, abs(float(ref[0])))
+    assert abs(float(err_adv) - float(ref[1])) < TOL * max(1.0, abs(float(ref[1])))
+    assert abs(float(err_cont) - float(ref[2])) < TOL * max(1e-3, abs(float(ref[2])))
+    assert grads_close(d_grads, ref[3], TOL) == []
+    assert grads_close(g_grads, ref[4], 2 * TOL) == []
+    sd = net_d.state_dict()
+    for k, v in ref[5].items():
+        assert rel_err(sd[k].cpu(), v) < TOL, k
