@@ -34,7 +34,11 @@ def test_planners_fit_lds_and_cover_the_problem(shape):
     E = _pkg('engine')
     n, cin, cout, k, s, h, w = shape
     f, d, g = E.ConvGeom(cin, cout, k, s, k // 2).plans(n, h, w)
-    for pl, (ho, wo) in ((f, (f.Ho, f.Wo)),) + (((d, (d.Ho, d.Wo)),) if d is not None else ()):
+    dgrad = [c[0] for c in d if c is not None] if isinstance(d, list) else ([d] if d is not None else [])
+    if s == 2:      # stride-2 data gradient: four output-parity classes that tile the input exactly
+        assert len(dgrad) == 4 and sum(c.Ho * c.Wo for c in dgrad) == h * w
+        assert sorted((c.KH, c.KW) for c in dgrad) == [(1, 1), (1, 2), (2, 1), (2, 2)]
+    for pl, (ho, wo) in [(f, (f.Ho, f.Wo))] + [(c, (c.Ho, c.Wo)) for c in dgrad]:
         p = pl.plan
         assert 0 < p.lds_bytes <= 160 * 1024
         assert p.tiles_y * p.TH >= ho and p.tiles_x * p.TW >= wo and p.n_groups * p.TN >= n
