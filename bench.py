@@ -30,6 +30,7 @@ PKG = 'single-image-super-resolution_amd'
 
 B, HR, LR = 16, 192, 96
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0                 # same guide: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
 
 def sub(name):
@@ -59,7 +60,7 @@ def make_step(device, rank, world):
     return step, net
 
 
-def dominant_kernel_roofline(device, iters=40):
+def dominant_kernel_roofline(device, precision, iters=40):
     """Live measurement of the dominant kernel: the trunk convolution 3x3, 64->64 at (16, 96, 96),
     launched exactly as inside the step (BatchNorm-apply + PReLU prologue, BatchNorm-statistics
     epilogue).  Algorithmic work per launch = 2*N*H*W*Cout*Cin*9 flops (10.87 GFLOP)."""
@@ -90,6 +91,16 @@ def dominant_kernel_roofline(device, iters=40):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * B * LR * LR * 64 * 64 * 9
+    if precision == 'bf16':
+        # bf16 matrix cores: the layer is HBM-bound.  Algorithmic bytes per launch (the input
+        # and the output tensor cross HBM once each; this round both are stored fp32): 2 * B*h*w*64 * 4 B
+        nbytes = 2.0 * B * LR * LR * 64 * 4
+        achieved = nbytes / (ms * 1e-3) / 1e9
+        return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / PEAK_HBM_GBS, 4), 'traffic': None,
+                'kernel': 'conv_mfma_bf16_kernel<*,2,1> (3x3 64->64 trunk conv, fp32 tensors in HBM)',
+                'launch_ms': round(ms, 4), 'alg_bytes_per_launch': nbytes,
+                'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 1)}
     achieved = flops / (ms * 1e-3) / 1e12
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
@@ -140,6 +151,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', choices=['bf16', 'fp32'], default=os.environ.get('SISR_PRECISION', 'bf16'),
+                    help='bf16: bf16 matrix cores with fp32 accumulate (BASELINE config 1); fp32: exact-fp32 parity build')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -151,6 +164,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=device)         # "nccl" is RCCL on ROCm
+    sub('engine').set_precision(args.precision)
     step, net = make_step(device, rank, world)
 
     def barrier():
@@ -173,13 +187,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
-        roof = dominant_kernel_roofline(device)
+        roof = dominant_kernel_roofline(device, args.precision)
         rec = {
             'metric': 'HR patches/sec (x2 generator fwd+bwd, LR 96x96 -> SR 192x192)',
             'value': round(world * B * args.steps / dt, 2), 'unit': 'HR patches/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': 'SRGAN x2 generator (16 blocks, 64 features, spectral norm) fwd+bwd+Adam with '
                                    'bicubic LR degradation and pixel-MSE x10, per-GPU batch 16 HR 192x192 patches',
                        'per_gpu_batch': B, 'hr': HR, 'lr': LR, 'parallelism': 'dp%d' % world,

@@ -116,6 +116,14 @@ typedef struct SisrWgradDesc {
 } SisrWgradDesc;
 
 int sisr_wgrad_plan(SisrWgradDesc *d, int32_t max_pixel_blocks);
+/* bf16 matrix-core variants (v_mfma_f32_32x32x16_bf16, fp32 accumulate; activations fp32 in HBM,
+ * converted while staged into LDS).  Same descriptors; `wpk` points at the bf16 image written by
+ * sisr_weights_prepare (wbf_fwd / wbf_dgrad).  Requirements: Cin % 32 == 0, KH*KW <= 9, NHWC
+ * operands; SISR_E_UNSUPPORTED otherwise (callers keep the fp32 kernels for those layers). */
+int sisr_conv2d_plan_bf16(SisrConvDesc *d);
+int sisr_conv2d_bf16(const SisrConvDesc *d, void *stream);
+int sisr_wgrad_plan_bf16(SisrWgradDesc *d, int32_t max_pixel_blocks);
+int sisr_conv2d_wgrad_bf16(const SisrWgradDesc *d, void *stream);
 int sisr_conv2d_wgrad_f32(const SisrWgradDesc *d, void *stream);
 /* out[i] = sum_s slab[s][i], i < elems (also used for the bias slabs) */
 int sisr_slab_reduce_f32(const float *slab, float *out, int32_t n_slabs, int64_t elems, void *stream);
@@ -143,6 +151,9 @@ typedef struct SisrWeightDesc {
     float *wpk_dcls[4];
     int32_t c_KH[4], c_KW[4], c_R0y[4], c_R0x[4];
     int32_t c_CK[4], c_PS[4], c_KROWP[4], c_n_chunk[4], c_CoutPad[4];
+    /* bf16 images for the bf16-MFMA kernels: [chunk of 32 in-channels][cout][tap*32 + ci] (or NULL) */
+    void *wbf_fwd, *wbf_dgrad;
+    int32_t bf_f_CoutPad, bf_d_CoutPad;
 } SisrWeightDesc;
 
 int sisr_weights_prepare(const SisrWeightDesc *table_dev, int32_t n, void *stream);
@@ -158,6 +169,8 @@ typedef struct SisrWeightGradDesc {
     float *grad_bias;         /* [Cout] out (original channel order) or NULL                  */
     int32_t Cout, Cin, KH, KW, shuffle2;
     int32_t CK, PS, KROWP, n_chunk, CoutPad;
+    int32_t layout;           /* 0: fp32 wgrad slabs [chunk][r][krow][co]; 1: bf16 wgrad slabs
+                                 [chunk32][tap][ci][co]                                          */
 } SisrWeightGradDesc;
 
 int sisr_weights_grad(const SisrWeightGradDesc *table_dev, int32_t n, void *stream);
@@ -265,6 +278,7 @@ int sisr_bicubic_bwd(const float *dy, const float *y_clamped, float *dx, int32_t
 int sisr_struct_sizes(int32_t *out, int32_t cap);
 int sisr_device_info(int32_t *n_cu, int32_t *lds_per_cu, char *arch, int32_t arch_len);
 int sisr_mfma_selftest(float *out_dev /* >= 32*32 floats */, void *stream);
+int sisr_tr16_selftest(int16_t *out_dev /* >= 64*8 shorts */, void *stream);
 const char *sisr_version(void);
 
 #ifdef __cplusplus

@@ -60,14 +60,15 @@ class WeightDesc(C.Structure):
                                      'd_CK', 'd_PS', 'd_KROWP', 'd_n_chunk', 'd_CoutPad')] +
                 [('wpk_dcls', _f * 4)] +
                 [(n, _i32 * 4) for n in ('c_KH', 'c_KW', 'c_R0y', 'c_R0x', 'c_CK', 'c_PS', 'c_KROWP',
-                                         'c_n_chunk', 'c_CoutPad')])
+                                         'c_n_chunk', 'c_CoutPad')] +
+                [('wbf_fwd', _f), ('wbf_dgrad', _f), ('bf_f_CoutPad', _i32), ('bf_d_CoutPad', _i32)])
 
 
 class WeightGradDesc(C.Structure):
     _fields_ = ([(n, _f) for n in ('dwpk', 'w_orig', 'u_used', 'v_used', 'sigma', 'grad', 'dbias_pk',
                                    'grad_bias')] +
                 [(n, _i32) for n in ('Cout', 'Cin', 'KH', 'KW', 'shuffle2', 'CK', 'PS', 'KROWP', 'n_chunk',
-                                     'CoutPad')])
+                                     'CoutPad', 'layout')])
 
 
 class BnBwdDesc(C.Structure):
@@ -82,6 +83,11 @@ _SIGS = {
     'sisr_conv2d_f32': [C.POINTER(ConvDesc), _f],
     'sisr_wgrad_plan': [C.POINTER(WgradDesc), _i32],
     'sisr_conv2d_wgrad_f32': [C.POINTER(WgradDesc), _f],
+    'sisr_conv2d_plan_bf16': [C.POINTER(ConvDesc)],
+    'sisr_conv2d_bf16': [C.POINTER(ConvDesc), _f],
+    'sisr_wgrad_plan_bf16': [C.POINTER(WgradDesc), _i32],
+    'sisr_conv2d_wgrad_bf16': [C.POINTER(WgradDesc), _f],
+    'sisr_tr16_selftest': [_f, _f],
     'sisr_slab_reduce_f32': [_f, _f, _i32, _i64, _f],
     'sisr_weights_prepare': [_f, _i32, _f],
     'sisr_weights_grad': [_f, _i32, _f],

@@ -1,0 +1,341 @@
+// conv_bf16.hip -- direct convolution on gfx950 with bf16 matrix cores (v_mfma_f32_32x32x16_bf16,
+// fp32 accumulate).  Same workgroup/tile structure and the same fused prologues/epilogues as
+// conv_fwd.hip; activations stay fp32 in HBM this round, they are converted to bf16 (RNE) while being
+// staged into LDS, so the layer moves its algorithmic bytes once and the contraction runs at the
+// bf16 MFMA rate (16x the exact-fp32 rate) -- which makes it HBM-bound, the regime BASELINE.json's
+// north_star asks for.  Channel chunks of 32; requirements: Cin % 32 == 0, KH*KW <= 9.
+//
+// LDS images (bf16):
+//   input  [pixel][PS = 40]   80-byte pixel stride: the 16-byte A fragments (8 consecutive channels
+//          of one pixel) of 16 consecutive pixels fall on 16 distinct 16-byte slots (conflict-free
+//          ds_read_b128); slots 32..39 are never read.
+//   weight [cout][WS = taps*32 + 8]   592-byte rows (= 16 * odd): B fragments conflict-free too.
+// MFMA 32x32x16 operand maps (cdna_hip_programming.md section 3): lane l holds A[row = l&31][k = 8*(l>>5)+j],
+// B[k = 8*(l>>5)+j][col = l&31], j = 0..7; C/D as for the fp32 32x32 form.
+#include "sisr_dev.h"
+
+#include <algorithm>
+#include <cstring>
+
+#include "sisr_bf16_stage.h"
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// one filter tap (32 input channels = two K=16 steps): all LDS fragment reads, then the MFMAs
+template <int MSUB, int NSUB>
+__device__ __forceinline__ void conv_bf16_tap(const __bf16* const (&ap)[MSUB], const __bf16* const (&bp)[NSUB],
+                                              int aoff, int boff, f32x16 (&acc)[MSUB][NSUB]) {
+    bf16x8 a[2][MSUB], b[2][NSUB];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+        for (int ms = 0; ms < MSUB; ++ms) a[kc][ms] = *reinterpret_cast<const bf16x8*>(ap[ms] + aoff + kc * 16);
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) b[kc][ns] = *reinterpret_cast<const bf16x8*>(bp[ns] + boff + kc * 16);
+    }
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns) acc[ms][ns] = mfma_bf16(a[kc][ms], b[kc][ns], acc[ms][ns]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MSUB + NSUB), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * MSUB * NSUB, 0);
+}
+
+template <int MSUB, int NSUB, int TAG>
+__global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const SisrConvDesc d) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const SisrConvPlan& p = d.plan;
+    constexpr int BM = 4 * MSUB * 32, BN = NSUB * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int S = d.stride;
+    const int IH = (p.TH - 1) * S + d.KH, IW = (p.TW - 1) * S + d.KW;
+    const int npix = p.TN * IH * IW;
+    const int taps = d.KH * d.KW;
+    const int WSG = taps * BF_CK, WS = WSG + 8;
+
+    int* row_off = reinterpret_cast<int*>(smem);
+    __bf16* lds_in = reinterpret_cast<__bf16*>(smem + BM);
+    __bf16* lds_w = lds_in + ((npix * BF_PS + 16 + 7) & ~7);
+    float* red = reinterpret_cast<float*>(lds_w);            // epilogue scratch (>= 5*BN floats)
+
+    int t = blockIdx.x;
+    const int txi = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int tyi = t % p.tiles_y, ng = t / p.tiles_y;
+    const int n0 = ng * p.TN, oy0 = tyi * p.TH, ox0 = txi * p.TW;
+    const int cout_base = blockIdx.y * BN;
+    const int thw = p.TH * p.TW, tile_rows = p.TN * thw;
+
+    for (int m = tid; m < BM; m += SISR_BLOCK) {
+        int off = -1;
+        if (m < tile_rows) {
+            const int tn = m / thw, rem = m - tn * thw;
+            const int ty = rem / p.TW, tx = rem - ty * p.TW;
+            const int n = n0 + tn, oy = oy0 + ty, ox = ox0 + tx;
+            if (n < d.N && oy < d.Ho && ox < d.Wo) {
+                const int py = oy * d.y_sy + d.y_oy, px = ox * d.y_sx + d.y_ox;
+                if (d.y_mode == SISR_Y_NHWC)
+                    off = ((n * d.y_H + py) * d.y_W + px) * d.Cout;
+                else if (d.y_mode == SISR_Y_NCHW)
+                    off = n * d.Cout * d.y_H * d.y_W + py * d.y_W + px;
+                else
+                    off = ((n * 2 * d.Ho + 2 * oy) * (2 * d.Wo) + 2 * ox) * (d.Cout >> 2);
+            }
+        }
+        row_off[m] = off;
+    }
+
+    const __bf16* ap[MSUB];
+    const __bf16* bp[NSUB];
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+        const int m = wave * (MSUB * 32) + ms * 32 + l31;
+        int base = 0;
+        if (m < tile_rows) {
+            const int tn = m / thw, rem = m - tn * thw;
+            const int ty = rem / p.TW, tx = rem - ty * p.TW;
+            base = ((tn * IH + ty * S) * IW + tx * S) * BF_PS;
+        }
+        ap[ms] = lds_in + base + 8 * kk;
+    }
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) bp[ns] = lds_w + (ns * 32 + l31) * WS + 8 * kk;
+
+    f32x16 acc[MSUB][NSUB];
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ms][ns][i] = 0.f;
+
+    OperandView ov;
+    ov.x1 = d.x1; ov.x2 = d.x2; ov.pa = d.pa; ov.pb = d.pb; ov.pd = d.pd; ov.ps = d.ps; ov.pt = d.pt;
+    ov.N = d.N; ov.H = d.H; ov.W = d.W; ov.C = d.Cin;
+    ov.mode = d.x_mode; ov.pro = d.pro_mode;
+    ov.slope = d.pro_slope_p ? d.pro_slope_p[0] : d.pro_slope;
+    const int iy_org = oy0 * S - d.pad_y, ix_org = ox0 * S - d.pad_x;
+    const int wvec_row = WSG >> 3;                       // 16-byte vectors per packed weight row
+    const int wvecs = BN * wvec_row;
+    const __bf16* wsrc0 = reinterpret_cast<const __bf16*>(d.wpk);
+
+    for (int chunk = 0; chunk < p.n_chunk; ++chunk) {
+        __syncthreads();   // all fragment reads of the previous chunk are done
+        stage_operand_tile_bf16(ov, lds_in, BF_PS, BF_CK, chunk * BF_CK, p.TN, IH, IW, n0, iy_org, ix_org, 1 << 30);
+        {   // packed weights of this chunk: [BN][WSG] contiguous bf16 -> LDS [BN][WS]
+            const bf16x8* src = reinterpret_cast<const bf16x8*>(wsrc0 + ((int64_t)chunk * p.CoutPad + cout_base) * WSG);
+            for (int v = tid; v < wvecs; v += SISR_BLOCK) {
+                const int j = v / wvec_row, k8 = v - j * wvec_row;
+                *reinterpret_cast<bf16x8*>(lds_w + j * WS + k8 * 8) = src[v];
+            }
+        }
+        __syncthreads();
+        int tap = 0;
+        for (int r = 0; r < d.KH; ++r)
+            for (int s = 0; s < d.KW; ++s, ++tap)
+                conv_bf16_tap<MSUB, NSUB>(ap, bp, (r * IW + s) * BF_PS, tap * BF_CK, acc);
+    }
+    __syncthreads();   // LDS (weights region) is reused as reduction scratch below
+
+    // ---- epilogue (identical to conv_fwd.hip: the 32x32 accumulator layout is dtype independent) ----
+    int col_off[NSUB];
+    bool col_ok[NSUB];
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+        const int cp = cout_base + ns * 32 + l31;
+        col_ok[ns] = cp < d.Cout;
+        int co = cp;
+        col_off[ns] = cp;
+        if (d.y_mode == SISR_Y_NHWC_SHUFFLE2) {
+            const int Cq = d.Cout >> 2;
+            const int ij = cp / Cq, c = cp - ij * Cq;
+            co = c * 4 + ij;
+            col_off[ns] = ((ij >> 1) * (2 * d.Wo) + (ij & 1)) * Cq + c;
+        } else if (d.y_mode == SISR_Y_NCHW) {
+            col_off[ns] = cp * d.y_H * d.y_W;
+        }
+        const float bv = (d.bias != nullptr && col_ok[ns]) ? d.bias[co] : 0.f;
+#pragma unroll
+        for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ms][ns][i] += bv;
+    }
+
+    if (d.stat_part != nullptr) {
+        float* meanb = red + 4 * BN;
+        const int vn = min(p.TN, d.N - n0), vh = min(p.TH, d.Ho - oy0), vw = min(p.TW, d.Wo - ox0);
+        const float cnt = (float)(vn * vh * vw);
+        float s[NSUB];
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) s[ns] = 0.f;
+#pragma unroll
+        for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = wave * (MSUB * 32) + ms * 32 + mfma_row(i, lane);
+                if (row_off[row] >= 0) {
+#pragma unroll
+                    for (int ns = 0; ns < NSUB; ++ns) s[ns] += acc[ms][ns][i];
+                }
+            }
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+            s[ns] += __shfl_xor(s[ns], 32);
+            if (kk == 0) red[wave * BN + ns * 32 + l31] = s[ns];
+        }
+        __syncthreads();
+        if (tid < BN) meanb[tid] = (red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid]) / cnt;
+        __syncthreads();
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+            const float mu = meanb[ns * 32 + l31];
+            float q = 0.f;
+#pragma unroll
+            for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = wave * (MSUB * 32) + ms * 32 + mfma_row(i, lane);
+                    if (row_off[row] >= 0) {
+                        const float dv = acc[ms][ns][i] - mu;
+                        q += dv * dv;
+                    }
+                }
+            s[ns] = q + __shfl_xor(q, 32);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)
+            if (kk == 0) red[wave * BN + ns * 32 + l31] = s[ns];
+        __syncthreads();
+        if (tid < BN && cout_base + tid < d.Cout) {
+            const float m2 = red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid];
+            float* sp = d.stat_part + (int64_t)blockIdx.x * 2 * d.Cout + cout_base + tid;
+            sp[0] = meanb[tid];
+            sp[d.Cout] = m2;
+        }
+        if (tid == 0 && blockIdx.y == 0) d.cnt_part[blockIdx.x] = cnt;
+    }
+
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = wave * (MSUB * 32) + ms * 32 + mfma_row(i, lane);
+            const int ro = row_off[row];
+            if (ro < 0) continue;
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns) {
+                if (!col_ok[ns]) continue;
+                const int64_t off = (int64_t)ro + col_off[ns];
+                float v = acc[ms][ns][i];
+                if (d.res != nullptr) v += d.res[off];
+                if (d.epi_act == SISR_EPI_TANH) v = tanhf(v);
+                d.y[off] = v;
+            }
+        }
+}
+
+// ---- host ------------------------------------------------------------------------------------------
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static int conv_bf16_lds_bytes(int BM, int TN, int TH, int TW, int S, int KH, int KW, int BN) {
+    const int IH = (TH - 1) * S + KH, IW = (TW - 1) * S + KW;
+    const int in_elems = (TN * IH * IW * BF_PS + 16 + 7) & ~7;
+    const int w_bytes = std::max(BN * (KH * KW * BF_CK + 8) * 2, 5 * BN * 4);
+    return BM * 4 + in_elems * 2 + w_bytes + 16;
+}
+
+extern "C" int sisr_conv2d_plan_bf16(SisrConvDesc* d) {
+    if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0) return SISR_E_BADARG;
+    if ((d->Cin % BF_CK) || d->KH * d->KW > 9) return SISR_E_UNSUPPORTED;
+    if (d->stride != 1 && d->stride != 2) return SISR_E_BADARG;
+    if (d->x_mode == SISR_X_NCHW) return SISR_E_UNSUPPORTED;
+    if (d->x_mode == SISR_X_NHWC_UNSHUFFLE2 && ((d->Cin >> 2) & 3)) return SISR_E_UNSUPPORTED;
+    if (d->y_mode == SISR_Y_NHWC_SHUFFLE2 && (d->Cout & 3)) return SISR_E_BADARG;
+    SisrConvPlan& p = d->plan;
+    std::memset(&p, 0, sizeof(p));
+    const int64_t ypix = std::max((int64_t)d->N * d->y_H * d->y_W, (int64_t)d->N * d->Ho * d->Wo);
+    if (ypix * d->Cout >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 31)) return SISR_E_TOOBIG;
+    p.nsub = d->Cout <= 32 ? 1 : 2;
+    const int BN = p.nsub * 32;
+    p.CoutPad = round_up(d->Cout, BN);
+    p.CK = BF_CK; p.PS = BF_PS; p.KROWP = d->KH * d->KW * BF_CK;
+    p.n_chunk = d->Cin / BF_CK;
+    const int64_t out_pix = (int64_t)d->N * d->Ho * d->Wo;
+    const int S = d->stride;
+    SisrConvPlan cand[2];
+    int cand_lds[2] = {0, 0};
+    double cand_cost[2] = {1e30, 1e30};
+    for (int mi = 0; mi < 2; ++mi) {
+        const int msub = 2 - mi, BM = 4 * msub * 32;
+        SisrConvPlan q = p;
+        q.msub = msub;
+        double best = -1.0;
+        int best_lds = 0;
+        for (int TW = 1; TW <= std::min(d->Wo, BM); ++TW) {
+            const int TH = std::min(d->Ho, BM / TW);
+            int TN = 1;
+            if (TH == d->Ho && TW == d->Wo) TN = std::max(1, std::min(d->N, BM / (TH * TW)));
+            const int lds = conv_bf16_lds_bytes(BM, TN, TH, TW, S, d->KH, d->KW, BN);
+            if (lds > 80 * 1024) continue;
+            const int ty = (d->Ho + TH - 1) / TH, tx = (d->Wo + TW - 1) / TW, ngr = (d->N + TN - 1) / TN;
+            const double eff = (double)out_pix / ((double)ty * tx * ngr * BM);
+            const double halo = (double)(TH * TW) * S * S / ((double)((TH - 1) * S + d->KH) * ((TW - 1) * S + d->KW));
+            const double score = eff * (0.6 + 0.4 * halo);
+            if (score > best + 1e-9) {
+                best = score; best_lds = lds;
+                q.TH = TH; q.TW = TW; q.TN = TN; q.tiles_y = ty; q.tiles_x = tx; q.n_groups = ngr;
+            }
+        }
+        if (best < 0) continue;
+        const int64_t blocks = (int64_t)q.tiles_y * q.tiles_x * q.n_groups * (p.CoutPad / BN);
+        cand[mi] = q;
+        cand_lds[mi] = best_lds;
+        cand_cost[mi] = (double)((blocks + 511) / 512) * BM * (mi == 0 ? 1.0 : 1.05);
+    }
+    const int pick = cand_cost[1] < cand_cost[0] ? 1 : 0;
+    if (cand_cost[pick] > 1e29) return SISR_E_TOOBIG;
+    p = cand[pick];
+    p.n_tiles = p.tiles_y * p.tiles_x * p.n_groups;
+    p.lds_bytes = cand_lds[pick];
+    p.wpk_elems = p.n_chunk * p.CoutPad * p.KROWP;       // bf16 elements
+    return 0;
+}
+
+template <int MSUB, int NSUB, int TAG>
+static int launch_conv_bf16(const SisrConvDesc* d, hipStream_t st) {
+    static int lds_max = 64 * 1024;
+    if (d->plan.lds_bytes > lds_max) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16_kernel<MSUB, NSUB, TAG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, d->plan.lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        lds_max = d->plan.lds_bytes;
+    }
+    const dim3 grid(d->plan.n_tiles, d->plan.CoutPad / (NSUB * 32));
+    hipLaunchKernelGGL((conv_mfma_bf16_kernel<MSUB, NSUB, TAG>), grid, dim3(SISR_BLOCK), d->plan.lds_bytes, st, *d);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_conv2d_bf16(const SisrConvDesc* d, void* stream) {
+    if (!d || !d->x1 || !d->wpk || !d->y) return SISR_E_BADARG;
+    if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
+    if (d->stat_part && (!d->cnt_part || d->y_mode != SISR_Y_NHWC)) return SISR_E_BADARG;
+    const SisrConvPlan& p = d->plan;
+    if (d->x_mode == SISR_X_NCHW || (d->Cin % BF_CK) || (d->x_mode == SISR_X_NHWC_UNSHUFFLE2 && ((d->Cin >> 2) & 3)))
+        return SISR_E_UNSUPPORTED;
+    if (p.CK != BF_CK || p.PS != BF_PS || p.n_tiles <= 0 || p.lds_bytes <= 0 || p.lds_bytes > 160 * 1024)
+        return SISR_E_BADARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool trunk = d->Cin == 64 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1;
+    if (p.msub == 2 && p.nsub == 2) return trunk ? launch_conv_bf16<2, 2, 1>(d, st) : launch_conv_bf16<2, 2, 0>(d, st);
+    if (p.msub == 2 && p.nsub == 1) return launch_conv_bf16<2, 1, 0>(d, st);
+    if (p.msub == 1 && p.nsub == 2) return trunk ? launch_conv_bf16<1, 2, 1>(d, st) : launch_conv_bf16<1, 2, 0>(d, st);
+    if (p.msub == 1 && p.nsub == 1) return launch_conv_bf16<1, 1, 0>(d, st);
+    return SISR_E_BADARG;
+}

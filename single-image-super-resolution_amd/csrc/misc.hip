@@ -43,6 +43,28 @@ extern "C" int sisr_device_info(int32_t* n_cu, int32_t* lds_per_cu, char* arch, 
     return 0;
 }
 
+// ds_read_b64_tr_b16 lane-role check: LDS holds a [16 pixels][32 channels] bf16-sized tile of shorts
+// (value = pixel*64 + channel); every lane addresses (pixel 8*(g>>1)+q, channel 16*(g&1)+4p) exactly as
+// wgrad_bf16.hip does and writes back the 8 shorts it received (two reads, pixels +0..3 and +4..7).
+typedef short ts4 __attribute__((ext_vector_type(4)));
+__global__ void tr16_selftest_kernel(short* out) {
+    __shared__ __attribute__((aligned(16))) short tile[16 * 40];
+    for (int i = threadIdx.x; i < 16 * 40; i += 64) tile[i] = (short)((i / 40) * 64 + (i % 40));
+    __syncthreads();
+    const int lane = threadIdx.x, grp = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const short* a = tile + (8 * (grp >> 1) + q) * 40 + 16 * (grp & 1) + 4 * p;
+    const ts4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ts4*)(a));
+    const ts4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ts4*)(a + 4 * 40));
+    for (int j = 0; j < 4; ++j) { out[lane * 8 + j] = lo[j]; out[lane * 8 + 4 + j] = hi[j]; }
+}
+
+extern "C" int sisr_tr16_selftest(short* out_dev, void* stream) {
+    if (!out_dev) return SISR_E_BADARG;
+    hipLaunchKernelGGL(tr16_selftest_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), out_dev);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sisr_struct_sizes(int32_t* out, int32_t cap) {
     const int32_t v[6] = {(int32_t)sizeof(SisrConvDesc), (int32_t)sizeof(SisrWgradDesc), (int32_t)sizeof(SisrWeightDesc),
                           (int32_t)sizeof(SisrWeightGradDesc), (int32_t)sizeof(SisrBnBwdDesc),

@@ -125,6 +125,45 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
             w.wpk_dgrad[e] = val;
         }
     }
+    // bf16 images for conv_bf16.hip: [chunk32][cp][tap*32 + cl]
+    if (w.wbf_fwd) {
+        __bf16* dst = reinterpret_cast<__bf16*>(w.wbf_fwd);
+        const int taps = w.KH * w.KW, WSG = taps * 32;
+        const int64_t total = (int64_t)(w.Cin / 32) * w.bf_f_CoutPad * WSG;
+        for (int64_t e = start; e < total; e += stride) {
+            int64_t tq = e;
+            const int kidx = (int)(tq % WSG); tq /= WSG;
+            const int cp = (int)(tq % w.bf_f_CoutPad);
+            const int chunk = (int)(tq / w.bf_f_CoutPad);
+            const int tap = kidx >> 5, cl = kidx & 31;
+            const int r = tap / w.KW, sx = tap - r * w.KW, ci = chunk * 32 + cl;
+            float val = 0.f;
+            if (cp < w.Cout) {
+                const int co = unpermute_cout(cp, w.Cout, w.shuffle2);
+                val = w.w_orig[(((int64_t)co * w.Cin + ci) * w.KH + r) * w.KW + sx] * inv;
+            }
+            dst[e] = (__bf16)val;
+        }
+    }
+    if (w.wbf_dgrad) {
+        __bf16* dst = reinterpret_cast<__bf16*>(w.wbf_dgrad);
+        const int taps = w.KH * w.KW, WSG = taps * 32;
+        const int64_t total = (int64_t)(w.Cout / 32) * w.bf_d_CoutPad * WSG;
+        for (int64_t e = start; e < total; e += stride) {
+            int64_t tq = e;
+            const int kidx = (int)(tq % WSG); tq /= WSG;
+            const int op = (int)(tq % w.bf_d_CoutPad);
+            const int chunk = (int)(tq / w.bf_d_CoutPad);
+            const int tap = kidx >> 5, il = kidx & 31;
+            const int r = tap / w.KW, sx = tap - r * w.KW, ip = chunk * 32 + il;
+            float val = 0.f;
+            if (op < w.Cin) {
+                const int co = unpermute_cout(ip, w.Cout, w.shuffle2);
+                val = w.w_orig[(((int64_t)co * w.Cin + op) * w.KH + (w.KH - 1 - r)) * w.KW + (w.KW - 1 - sx)] * inv;
+            }
+            dst[e] = (__bf16)val;
+        }
+    }
     // stride-2 data gradient: one packed image per output parity class
     for (int cls = 0; cls < 4; ++cls) {
         float* dst = w.wpk_dcls[cls];
@@ -164,6 +203,10 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_grad_kernel(const SisrWeig
         const int ci = (int)(tq % w.Cin);
         const int co = (int)(tq / w.Cin);
         const int cp = w.shuffle2 ? ((co & 3) * Cq + (co >> 2)) : co;
+        if (w.layout == 1) {     // wgrad_bf16.hip slabs: [chunk32][tap][ci 32][CoutPad]
+            const int chunk = ci >> 5, cl = ci & 31;
+            return ((int64_t)(chunk * w.KH * w.KW + r * w.KW + s) * 32 + cl) * w.CoutPad + cp;
+        }
         const int chunk = ci / w.CK, cl = ci - chunk * w.CK;
         const int krow = s * w.PS + cl;
         return ((int64_t)(chunk * w.KH + r) * w.KROWP + krow) * w.CoutPad + cp;

@@ -13,6 +13,19 @@ import torch
 from . import _lib as L
 
 
+import os
+
+# 'fp32': exact-fp32 MFMA everywhere (the parity build).  'bf16': layers with Cin % 32 == 0 run their
+# contraction on the bf16 matrix cores (fp32 accumulate, fp32 statistics, fp32 tensors in HBM).
+PRECISION = os.environ.get('SISR_PRECISION', 'fp32')
+
+
+def set_precision(p):
+    global PRECISION
+    assert p in ('fp32', 'bf16')
+    PRECISION = p
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -96,7 +109,9 @@ class ConvGeom:
         return (d, r0y, r0x)
 
     def plans(self, n, h, w, max_pixel_blocks=512):
-        key = (n, h, w)
+        """-> (fwd desc, dgrad desc | [4 class descs] | None, wgrad desc, kinds) where kinds =
+        (fwd_bf16, dgrad_bf16, wgrad_bf16) tells which kernel family each template was planned for."""
+        key = (n, h, w, PRECISION)
         if key in self._plans:
             return self._plans[key]
         lib = L.lib()
@@ -109,8 +124,12 @@ class ConvGeom:
         f.y_oy = f.y_ox = 0
         f.y_H, f.y_W = ho, wo
         f.y_mode = L.Y_SHUFFLE2 if self.shuffle2 else L.Y_NHWC
-        L.check(lib.sisr_conv2d_plan(C.byref(f)), 'sisr_conv2d_plan(fwd)')
+        want_bf16 = PRECISION == 'bf16' and self.k * self.k <= 9
+        f_bf = want_bf16 and self.cin % 32 == 0 and lib.sisr_conv2d_plan_bf16(C.byref(f)) == 0
+        if not f_bf:
+            L.check(lib.sisr_conv2d_plan(C.byref(f)), 'sisr_conv2d_plan(fwd)')
         d = None
+        d_bf = False
         if self.stride == 1:
             d = L.ConvDesc()      # data gradient: conv over dy with flipped taps, roles swapped
             d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, ho, wo, self.cout, h, w, self.cin
@@ -119,16 +138,21 @@ class ConvGeom:
             d.pad_y = d.pad_x = self.k - 1 - self.pad
             d.y_sy = d.y_sx = 1
             d.y_H, d.y_W = h, w
-            L.check(lib.sisr_conv2d_plan(C.byref(d)), 'sisr_conv2d_plan(dgrad)')
+            d_bf = want_bf16 and self.cout % 32 == 0 and lib.sisr_conv2d_plan_bf16(C.byref(d)) == 0
+            if not d_bf:
+                L.check(lib.sisr_conv2d_plan(C.byref(d)), 'sisr_conv2d_plan(dgrad)')
         else:
             d = [self._s2_class_plan(lib, n, h, w, ho, wo, py, px) for py in (0, 1) for px in (0, 1)]
         g = L.WgradDesc()
         g.N, g.H, g.W, g.Cin, g.Ho, g.Wo, g.Cout = n, h, w, self.cin, ho, wo, self.cout
         g.KH = g.KW = self.k
         g.stride, g.pad_y, g.pad_x = self.stride, self.pad, self.pad
-        L.check(lib.sisr_wgrad_plan(C.byref(g), max_pixel_blocks), 'sisr_wgrad_plan')
+        g_bf = (want_bf16 and self.cin % 32 == 0 and self.cout % 4 == 0 and
+                lib.sisr_wgrad_plan_bf16(C.byref(g), max_pixel_blocks) == 0)
+        if not g_bf:
+            L.check(lib.sisr_wgrad_plan(C.byref(g), max_pixel_blocks), 'sisr_wgrad_plan')
         g.slab_stride = g.slab_elems + g.CoutPad
-        self._plans[key] = (f, d, g)
+        self._plans[key] = (f, d, g, (bool(f_bf), bool(d_bf), bool(g_bf)))
         return self._plans[key]
 
 
@@ -150,7 +174,7 @@ class ConvRef:
 
 class Prepared:
     """Per-forward products of sisr_weights_prepare for one conv (kept for the backward pass)."""
-    __slots__ = ('ref', 'plans', 'wpk_fwd', 'wpk_dgrad', 'sigma', 'u_used', 'v_used')
+    __slots__ = ('ref', 'plans', 'kinds', 'wpk_fwd', 'wpk_dgrad', 'sigma', 'u_used', 'v_used')
 
 
 def prepare_weights(items, training, need_dgrad=True):
@@ -161,9 +185,9 @@ def prepare_weights(items, training, need_dgrad=True):
     total, small = 0, 0
     metas = []
     for ref, n, h, w in items:
-        f, d, g = ref.geom.plans(n, h, w)
+        f, d, g, kinds = ref.geom.plans(n, h, w)
         off_f = total
-        total += _align4(f.plan.wpk_elems)
+        total += _align4((f.plan.wpk_elems + 1) // 2 if kinds[0] else f.plan.wpk_elems)   # bf16: 2 per float slot
         off_d = None
         if need_dgrad and isinstance(d, list):
             off_d = []
@@ -173,7 +197,7 @@ def prepare_weights(items, training, need_dgrad=True):
                     total += _align4(cls[0].plan.wpk_elems)
         elif need_dgrad and d is not None:
             off_d = total
-            total += _align4(d.plan.wpk_elems)
+            total += _align4((d.plan.wpk_elems + 1) // 2 if kinds[1] else d.plan.wpk_elems)
         off_s = small
         small += 4 + (_align4(ref.geom.cout) + _align4(ref.geom.cin * ref.geom.k * ref.geom.k) if ref.u is not None else 0)
         metas.append((off_f, off_d, off_s))
@@ -182,21 +206,28 @@ def prepare_weights(items, training, need_dgrad=True):
     table = (L.WeightDesc * len(items))()
     out = []
     for i, ((ref, n, h, w), (off_f, off_d, off_s)) in enumerate(zip(items, metas)):
-        f, d, g = ref.geom.plans(n, h, w)
+        f, d, g, kinds = ref.geom.plans(n, h, w)
         gm = ref.geom
         p = Prepared()
-        p.ref, p.plans = ref, (f, d, g)
-        p.wpk_fwd = big[off_f:off_f + f.plan.wpk_elems]
+        p.ref, p.plans, p.kinds = ref, (f, d, g), kinds
+        p.wpk_fwd = big[off_f:off_f + ((f.plan.wpk_elems + 1) // 2 if kinds[0] else f.plan.wpk_elems)]
         if isinstance(off_d, list):
             p.wpk_dgrad = [None if o is None else big[o:o + cls[0].plan.wpk_elems] for o, cls in zip(off_d, d)]
         else:
-            p.wpk_dgrad = big[off_d:off_d + d.plan.wpk_elems] if off_d is not None else None
+            p.wpk_dgrad = (big[off_d:off_d + ((d.plan.wpk_elems + 1) // 2 if kinds[1] else d.plan.wpk_elems)]
+                           if off_d is not None else None)
         p.sigma = sm[off_s:off_s + 1]
         t = table[i]
         t.w_orig = ref.weight.data_ptr()
         t.sigma = p.sigma.data_ptr()
-        t.wpk_fwd = p.wpk_fwd.data_ptr()
-        t.wpk_dgrad = None if isinstance(p.wpk_dgrad, list) else _ptr(p.wpk_dgrad)
+        if kinds[0]:
+            t.wbf_fwd, t.bf_f_CoutPad = p.wpk_fwd.data_ptr(), f.plan.CoutPad
+        else:
+            t.wpk_fwd = p.wpk_fwd.data_ptr()
+        if kinds[1]:
+            t.wbf_dgrad, t.bf_d_CoutPad = p.wpk_dgrad.data_ptr(), d.plan.CoutPad
+        else:
+            t.wpk_dgrad = None if isinstance(p.wpk_dgrad, list) else _ptr(p.wpk_dgrad)
         t.Cout, t.Cin, t.KH, t.KW = gm.cout, gm.cin, gm.k, gm.k
         t.training, t.shuffle2 = int(training), int(gm.shuffle2)
         t.f_CK, t.f_PS, t.f_KROWP, t.f_n_chunk, t.f_CoutPad = (f.plan.CK, f.plan.PS, f.plan.KROWP,
@@ -210,7 +241,7 @@ def prepare_weights(items, training, need_dgrad=True):
                 t.c_KH[ci], t.c_KW[ci], t.c_R0y[ci], t.c_R0x[ci] = cd.KH, cd.KW, r0y, r0x
                 t.c_CK[ci], t.c_PS[ci], t.c_KROWP[ci] = cd.plan.CK, cd.plan.PS, cd.plan.KROWP
                 t.c_n_chunk[ci], t.c_CoutPad[ci] = cd.plan.n_chunk, cd.plan.CoutPad
-        elif off_d is not None:
+        elif off_d is not None and not kinds[1]:
             t.d_CK, t.d_PS, t.d_KROWP, t.d_n_chunk, t.d_CoutPad = (d.plan.CK, d.plan.PS, d.plan.KROWP,
                                                                      d.plan.n_chunk, d.plan.CoutPad)
         p.u_used = p.v_used = None
@@ -258,7 +289,10 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
         sp = torch.empty((f.plan.n_tiles, 2, gm.cout), dtype=torch.float32, device=dev)
         cp = torch.empty((f.plan.n_tiles,), dtype=torch.float32, device=dev)
         f.stat_part, f.cnt_part = sp.data_ptr(), cp.data_ptr()
-    L.check(lib.sisr_conv2d_f32(C.byref(f), _stream()), 'sisr_conv2d_f32(fwd)')
+    if prep.kinds[0]:
+        L.check(lib.sisr_conv2d_bf16(C.byref(f), _stream()), 'sisr_conv2d_bf16(fwd)')
+    else:
+        L.check(lib.sisr_conv2d_f32(C.byref(f), _stream()), 'sisr_conv2d_f32(fwd)')
     return out, sp, cp
 
 
@@ -291,7 +325,10 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC):
         out = torch.empty((d.N, d.Ho, d.Wo, gm.cin), dtype=torch.float32, device=dev)
     dy_op.fill(d)
     d.wpk, d.bias, d.res, d.y = prep.wpk_dgrad.data_ptr(), None, _ptr(res), out.data_ptr()
-    L.check(lib.sisr_conv2d_f32(C.byref(d), _stream()), 'sisr_conv2d_f32(dgrad)')
+    if prep.kinds[1]:
+        L.check(lib.sisr_conv2d_bf16(C.byref(d), _stream()), 'sisr_conv2d_bf16(dgrad)')
+    else:
+        L.check(lib.sisr_conv2d_f32(C.byref(d), _stream()), 'sisr_conv2d_f32(dgrad)')
     return out
 
 
@@ -308,7 +345,10 @@ def conv_wgrad(prep, x_op, dy_op):
     dy_op.fill(g, g=True)
     g.slab = slab.data_ptr()
     g.bias_slab = slab.data_ptr() + 4 * g.slab_elems
-    L.check(lib.sisr_conv2d_wgrad_f32(C.byref(g), _stream()), 'sisr_conv2d_wgrad_f32')
+    if prep.kinds[2]:
+        L.check(lib.sisr_conv2d_wgrad_bf16(C.byref(g), _stream()), 'sisr_conv2d_wgrad_bf16')
+    else:
+        L.check(lib.sisr_conv2d_wgrad_f32(C.byref(g), _stream()), 'sisr_conv2d_wgrad_f32')
     red = torch.empty((stride,), dtype=torch.float32, device=dev)
     L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), red.data_ptr(), g.n_slabs, stride, _stream()),
             'sisr_slab_reduce_f32')
@@ -344,6 +384,7 @@ class WeightGradBatch:
             t.grad_bias = _ptr(gb)
             t.Cout, t.Cin, t.KH, t.KW, t.shuffle2 = gm.cout, gm.cin, gm.k, gm.k, int(gm.shuffle2)
             t.CK, t.PS, t.KROWP, t.n_chunk, t.CoutPad = g.CK, g.PS, g.KROWP, g.n_chunk, g.CoutPad
+            t.layout = 1 if p.kinds[2] else 0
             res[id(p.ref)] = (gw, gb)
         tab = _table_to_device(table, dev)
         L.check(lib.sisr_weights_grad(tab.data_ptr(), len(self.items), _stream()), 'sisr_weights_grad')

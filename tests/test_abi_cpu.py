@@ -33,7 +33,8 @@ def test_library_exports_every_declared_symbol():
 def test_planners_fit_lds_and_cover_the_problem(shape):
     E = _pkg('engine')
     n, cin, cout, k, s, h, w = shape
-    f, d, g = E.ConvGeom(cin, cout, k, s, k // 2).plans(n, h, w)
+    f, d, g, kinds = E.ConvGeom(cin, cout, k, s, k // 2).plans(n, h, w)
+    assert kinds == (False, False, False)          # default precision: the exact-fp32 kernels
     dgrad = [c[0] for c in d if c is not None] if isinstance(d, list) else ([d] if d is not None else [])
     if s == 2:      # stride-2 data gradient: four output-parity classes that tile the input exactly
         assert len(dgrad) == 4 and sum(c.Ho * c.Wo for c in dgrad) == h * w

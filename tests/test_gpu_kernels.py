@@ -219,3 +219,54 @@ def test_bicubic_against_golden(L, golden_dir):
         dx = torch.empty_like(x)
         L.check(lib.sisr_bicubic_bwd(dy.data_ptr(), None, dx.data_ptr(), n * c, h, w, oh, ow, st), 'bicubic_bwd')
         assert float((dx.cpu() - torch.from_numpy(z['grad_x%d' % i])).abs().max()) < 2e-5
+
+
+# ---- bf16 matrix-core kernel family (fp32 tensors in HBM, bf16 MFMA, fp32 accumulate) -------------------
+BF16_TOL = 2e-2      # bf16 has 8 significant bits: operands rounded to 2^-9 relative, fp32 accumulation
+
+
+def test_tr16_lane_roles(L):
+    """ds_read_b64_tr_b16 hands lane (group g, i) channel 16*(g&1)+i of pixels 8*(g>>1)+0..7"""
+    out = torch.zeros(64 * 8, dtype=torch.int16, device='cuda')
+    L.check(L.lib().sisr_tr16_selftest(out.data_ptr(), torch.cuda.current_stream().cuda_stream), 'tr16')
+    got = out.cpu().reshape(64, 8)
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        exp = [(8 * (g >> 1) + j) * 64 + 16 * (g & 1) + i for j in range(8)]
+        assert got[lane].tolist() == exp, (lane, got[lane].tolist(), exp)
+
+
+BF16_CASES = [(2, 64, 64, 3, 1, 12, 12), (1, 64, 64, 3, 1, 37, 29), (2, 32, 128, 3, 1, 8, 8), (2, 128, 64, 3, 1, 6, 6),
+              (2, 64, 256, 3, 1, 16, 16), (2, 64, 128, 3, 2, 16, 16), (1, 64, 64, 3, 1, 96, 96)]
+
+
+@pytest.mark.parametrize('case', BF16_CASES)
+def test_conv_bf16_forward_dgrad_wgrad(E, L, case):
+    n, cin, cout, k, stride, h, w = case
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((cout, cin, k, k), 2, (1.0 / (cin * k * k)) ** 0.5 * 1.7)
+    b = _rand((cout,), 3, 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, br, stride=stride, padding=k // 2)
+    r = _rand(tuple(y_ref.shape), 4)
+    (y_ref * r).sum().backward()
+    E.set_precision('bf16')
+    try:
+        geom = E.ConvGeom(cin, cout, k, stride, k // 2)
+        ref = FakeConv(wt.cuda(), b.cuda(), geom)
+        preps, keep = E.prepare_weights([(ref, n, h, w)], training=True)
+        p = preps[0]
+        assert p.kinds[0] and p.kinds[2] and (p.kinds[1] or stride == 2)
+        xd, rd = nhwc(x).cuda(), nhwc(r).cuda()
+        y, sp, cp = E.conv_forward(p, E.Operand.plain(xd), bias=ref.bias, stats=True)
+        assert maxrel(nchw(y), y_ref) < BF16_TOL, 'forward'
+        red = E.conv_wgrad(p, E.Operand.plain(xd), E.Operand.plain(rd))
+        wg = E.WeightGradBatch()
+        wg.add(p, red)
+        gw, gb = wg.run()[id(ref)]
+        assert maxrel(gw, wr.grad) < BF16_TOL, 'wgrad'
+        assert maxrel(gb, br.grad) < BF16_TOL, 'bias grad'
+        dx = E.conv_dgrad(p, E.Operand.plain(rd))
+        assert maxrel(nchw(dx), xr.grad) < BF16_TOL, 'dgrad'
+    finally:
+        E.set_precision('fp32')
