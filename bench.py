@@ -46,18 +46,43 @@ def make_step(device, rank, world):
     hr = (torch.rand((B, 3, HR, HR), generator=g) * 2 - 1).to(device)
     reducer = sub('distributed').GradReducer(list(net.parameters()), world) if world > 1 else None
 
-    def step():
+    def fwd_bwd():
         lr = utils.lr_from_hr(hr, (LR, LR), device=device)
         fake = net(lr)
         loss = 10.0 * torch.mean(torch.pow(hr - fake, 2))
         net.zero_grad(set_to_none=True)
         loss.backward()
+        return loss
+
+    state = {'graph': None, 'loss': None}
+
+    def capture():
+        """Record the forward+backward launch sequence (~350 kernels) once into a HIP graph; afterwards a step
+        replays it -- same kernels, same work, no per-launch host cost.  Gradients are static tensors of the
+        graph's pool; the gradient all-reduce and the Adam step stay ordinary stream work after the replay."""
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            state['loss'] = fwd_bwd()
+        state['graph'] = g
+
+    def step():
+        if state['graph'] is not None:
+            state['graph'].replay()
+            loss = state['loss']
+        else:
+            loss = fwd_bwd()
         if reducer is not None:
             reducer.all_reduce_mean()
         opt.step()
         return loss
 
-    return step, net
+    return step, net, capture
 
 
 def dominant_kernel_roofline(device, precision, iters=40):
@@ -151,6 +176,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a HIP graph')
     ap.add_argument('--precision', choices=['bf16', 'fp32'], default=os.environ.get('SISR_PRECISION', 'bf16'),
                     help='bf16: bf16 matrix cores with fp32 accumulate (BASELINE config 1); fp32: exact-fp32 parity build')
     args = ap.parse_args()
@@ -165,7 +191,14 @@ def main():
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=device)         # "nccl" is RCCL on ROCm
     sub('engine').set_precision(args.precision)
-    step, net = make_step(device, rank, world)
+    step, net, capture = make_step(device, rank, world)
+    graphed = False
+    if not args.no_graph:
+        try:
+            capture()
+            graphed = True
+        except Exception as e:                                   # noqa: BLE001
+            print('HIP graph capture failed (%s: %s); running eagerly' % (type(e).__name__, e), file=sys.stderr)
 
     def barrier():
         if world > 1:
@@ -196,7 +229,7 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': 'SRGAN x2 generator (16 blocks, 64 features, spectral norm) fwd+bwd+Adam with '
                                    'bicubic LR degradation and pixel-MSE x10, per-GPU batch 16 HR 192x192 patches',
-                       'per_gpu_batch': B, 'hr': HR, 'lr': LR, 'parallelism': 'dp%d' % world,
+                       'per_gpu_batch': B, 'hr': HR, 'lr': LR, 'parallelism': 'dp%d' % world, 'hip_graph': graphed,
                        'final_loss': round(float(loss.item()), 6)},
             'roofline': roof,
         }

@@ -173,7 +173,8 @@ typedef struct SisrWeightGradDesc {
                                  [chunk32][tap][ci][co]                                          */
 } SisrWeightGradDesc;
 
-int sisr_weights_grad(const SisrWeightGradDesc *table_dev, int32_t n, void *stream);
+/* dot_work: >= 16*n floats of scratch */
+int sisr_weights_grad(const SisrWeightGradDesc *table_dev, int32_t n, float *dot_work, void *stream);
 
 /* ---- BatchNorm2d (training) pieces that are not fused into the convolutions ------------------
  * finalize: merge the per-tile (mean, M2) partials (Chan et al.), produce the fused apply

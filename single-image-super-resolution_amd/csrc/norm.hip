@@ -9,44 +9,47 @@
 #include <algorithm>
 
 // ---- forward statistics: Chan-merge of the per-tile (count, mean, M2) partials ------------------
-__global__ void __launch_bounds__(SISR_BLOCK) bn_finalize_kernel(
+// Merge of the per-tile (count, mean_b, M2_b) partials in two fully parallel passes (no serial chain):
+//   N = sum n_b ; mean = sum n_b*mean_b / N ; M2 = sum [ M2_b + n_b*(mean_b - mean)^2 ]
+// (algebraically Chan et al.'s pairwise update summed over all tiles; all sums in double).
+// Workgroup = 16 channels x 64 tile-splits (1024 threads).
+#define BNF_SPLITS 64
+__device__ __forceinline__ double bnf_reduce(double v, double (*sh)[16], int split, int cl) {
+    sh[split][cl] = v;
+    __syncthreads();
+    for (int half = BNF_SPLITS / 2; half >= 1; half >>= 1) {
+        if (split < half) sh[split][cl] += sh[split + half][cl];
+        __syncthreads();
+    }
+    const double r = sh[0][cl];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(
     const float* __restrict__ stat_part, const float* __restrict__ cnt_part, int n_tiles, int C,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
     float* save_invstd) {
-    // 16 channels x 16 tile-splits per workgroup; splits merged pairwise through LDS
-    __shared__ double sh_n[16][16], sh_mean[16][16], sh_m2[16][16];
+    __shared__ double sh[BNF_SPLITS][16];
     const int cl = threadIdx.x & 15, split = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    if (c < C) {
-        for (int t = split; t < n_tiles; t += 16) {
-            const double nb = cnt_part[t];
-            if (nb <= 0.0) continue;
-            const double mb = stat_part[(int64_t)t * 2 * C + c];
-            const double qb = stat_part[(int64_t)t * 2 * C + C + c];
-            const double nn = n + nb, delta = mb - mean;
-            mean += delta * (nb / nn);
-            m2 += qb + delta * delta * (n * nb / nn);
-            n = nn;
-        }
+    const int c = min(blockIdx.x * 16 + cl, C - 1);
+    double n = 0.0, s = 0.0;
+    for (int t = split; t < n_tiles; t += BNF_SPLITS) {
+        const double nb = cnt_part[t];
+        n += nb;
+        s += nb * (double)stat_part[(int64_t)t * 2 * C + c];
     }
-    sh_n[split][cl] = n; sh_mean[split][cl] = mean; sh_m2[split][cl] = m2;
-    __syncthreads();
-    for (int half = 8; half >= 1; half >>= 1) {
-        if (split < half) {
-            const double nb = sh_n[split + half][cl];
-            if (nb > 0.0) {
-                const double nn = n + nb, delta = sh_mean[split + half][cl] - mean;
-                mean += delta * (nb / nn);
-                m2 += sh_m2[split + half][cl] + delta * delta * (n * nb / nn);
-                n = nn;
-            }
-            sh_n[split][cl] = n; sh_mean[split][cl] = mean; sh_m2[split][cl] = m2;
-        }
-        __syncthreads();
+    n = bnf_reduce(n, sh, split, cl);
+    const double mean = bnf_reduce(s, sh, split, cl) / n;
+    double m2 = 0.0;
+    for (int t = split; t < n_tiles; t += BNF_SPLITS) {
+        const double nb = cnt_part[t];
+        const double dm = (double)stat_part[(int64_t)t * 2 * C + c] - mean;
+        m2 += (double)stat_part[(int64_t)t * 2 * C + C + c] + nb * dm * dm;
     }
-    if (split == 0 && c < C) {
+    m2 = bnf_reduce(m2, sh, split, cl);
+    if (split == 0 && blockIdx.x * 16 + cl < C) {
         const double var = m2 / n;                       // biased (normalisation)
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = gamma[c] * invstd;
@@ -217,7 +220,7 @@ extern "C" int sisr_bn_finalize(const float* stat_part, const float* cnt_part, i
     if (!stat_part || !cnt_part || n_tiles <= 0 || C <= 0 || !gamma || !beta || !running_mean || !running_var ||
         !scale || !shift || !save_mean || !save_invstd)
         return SISR_E_BADARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(SISR_BLOCK), 0, S_(stream), stat_part,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), stat_part,
                        cnt_part, n_tiles, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
                        save_mean, save_invstd);
     SISR_CHECK_LAUNCH();

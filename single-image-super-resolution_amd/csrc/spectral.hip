@@ -188,47 +188,66 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
     }
 }
 
-// weight-gradient epilogue: one workgroup per weight
-__global__ void __launch_bounds__(SISR_BLOCK) weights_grad_kernel(const SisrWeightGradDesc* table) {
+// weight-gradient epilogue, two launches over grid (n_weights, WG_PARTS):
+//   1. partial <G, W_orig> per (weight, part)  -> dot_part[w][part]   (deterministic order)
+//   2. every part sums the WG_PARTS partials of its weight and writes its share of the OIHW gradient
+#define WG_PARTS 16
+__device__ __forceinline__ int64_t wg_packed_index(const SisrWeightGradDesc& w, int64_t e) {
+    const int Cq = w.Cout >> 2;
+    int64_t tq = e;
+    const int s = (int)(tq % w.KW); tq /= w.KW;
+    const int r = (int)(tq % w.KH); tq /= w.KH;
+    const int ci = (int)(tq % w.Cin);
+    const int co = (int)(tq / w.Cin);
+    const int cp = w.shuffle2 ? ((co & 3) * Cq + (co >> 2)) : co;
+    if (w.layout == 1) {     // wgrad_bf16.hip slabs: [chunk32][tap][ci 32][CoutPad]
+        const int chunk = ci >> 5, cl = ci & 31;
+        return ((int64_t)(chunk * w.KH * w.KW + r * w.KW + s) * 32 + cl) * w.CoutPad + cp;
+    }
+    const int chunk = ci / w.CK, cl = ci - chunk * w.CK;
+    const int krow = s * w.PS + cl;
+    return ((int64_t)(chunk * w.KH + r) * w.KROWP + krow) * w.CoutPad + cp;
+}
+
+__global__ void __launch_bounds__(SISR_BLOCK) weights_grad_dot_kernel(const SisrWeightGradDesc* table,
+                                                                     float* dot_part) {
     __shared__ float scratch[8];
+    const SisrWeightGradDesc w = table[blockIdx.x];
+    float part = 0.f;
+    if (w.u_used != nullptr && w.grad != nullptr) {
+        const int64_t total = (int64_t)w.Cout * w.Cin * w.KH * w.KW;
+        for (int64_t e = (int64_t)blockIdx.y * SISR_BLOCK + threadIdx.x; e < total; e += (int64_t)WG_PARTS * SISR_BLOCK)
+            part += w.dwpk[wg_packed_index(w, e)] * w.w_orig[e];
+    }
+    const float tot = block_sum(part, scratch);
+    if (threadIdx.x == 0) dot_part[blockIdx.x * WG_PARTS + blockIdx.y] = tot;
+}
+
+__global__ void __launch_bounds__(SISR_BLOCK) weights_grad_kernel(const SisrWeightGradDesc* table,
+                                                                 const float* dot_part) {
     const SisrWeightGradDesc w = table[blockIdx.x];
     const int tid = threadIdx.x;
     const int cols = w.Cin * w.KH * w.KW;
     const int64_t total = (int64_t)w.Cout * cols;
     const int Cq = w.Cout >> 2;
-    auto packed_index = [&](int64_t e) -> int64_t {
-        int64_t tq = e;
-        const int s = (int)(tq % w.KW); tq /= w.KW;
-        const int r = (int)(tq % w.KH); tq /= w.KH;
-        const int ci = (int)(tq % w.Cin);
-        const int co = (int)(tq / w.Cin);
-        const int cp = w.shuffle2 ? ((co & 3) * Cq + (co >> 2)) : co;
-        if (w.layout == 1) {     // wgrad_bf16.hip slabs: [chunk32][tap][ci 32][CoutPad]
-            const int chunk = ci >> 5, cl = ci & 31;
-            return ((int64_t)(chunk * w.KH * w.KW + r * w.KW + s) * 32 + cl) * w.CoutPad + cp;
-        }
-        const int chunk = ci / w.CK, cl = ci - chunk * w.CK;
-        const int krow = s * w.PS + cl;
-        return ((int64_t)(chunk * w.KH + r) * w.KROWP + krow) * w.CoutPad + cp;
-    };
-    if (w.grad_bias != nullptr && w.dbias_pk != nullptr) {
+    if (blockIdx.y == 0 && w.grad_bias != nullptr && w.dbias_pk != nullptr) {
         for (int co = tid; co < w.Cout; co += SISR_BLOCK)
             w.grad_bias[co] = w.dbias_pk[w.shuffle2 ? ((co & 3) * Cq + (co >> 2)) : co];
     }
     if (w.grad == nullptr) return;
+    const int64_t start = (int64_t)blockIdx.y * SISR_BLOCK + tid, stride = (int64_t)WG_PARTS * SISR_BLOCK;
     if (w.u_used == nullptr) {
-        for (int64_t e = tid; e < total; e += SISR_BLOCK) w.grad[e] = w.dwpk[packed_index(e)];
+        for (int64_t e = start; e < total; e += stride) w.grad[e] = w.dwpk[wg_packed_index(w, e)];
         return;
     }
     const float sigma = w.sigma[0];
-    float part = 0.f;
-    for (int64_t e = tid; e < total; e += SISR_BLOCK) part += w.dwpk[packed_index(e)] * w.w_orig[e];
-    // <G, W> with W = W_orig / sigma
-    const float gw = block_sum(part, scratch) / sigma;
+    float dot = 0.f;
+    for (int k = 0; k < WG_PARTS; ++k) dot += dot_part[blockIdx.x * WG_PARTS + k];
+    const float gw = dot / sigma;          // <G, W> with W = W_orig / sigma
     const float inv = 1.f / sigma;
-    for (int64_t e = tid; e < total; e += SISR_BLOCK) {
+    for (int64_t e = start; e < total; e += stride) {
         const int co = (int)(e / cols), col = (int)(e - (int64_t)co * cols);
-        w.grad[e] = (w.dwpk[packed_index(e)] - gw * w.u_used[co] * w.v_used[col]) * inv;
+        w.grad[e] = (w.dwpk[wg_packed_index(w, e)] - gw * w.u_used[co] * w.v_used[col]) * inv;
     }
 }
 
@@ -244,10 +263,12 @@ extern "C" int sisr_weights_prepare(const SisrWeightDesc* table_dev, int32_t n, 
     return 0;
 }
 
-extern "C" int sisr_weights_grad(const SisrWeightGradDesc* table_dev, int32_t n, void* stream) {
-    if (!table_dev || n <= 0) return SISR_E_BADARG;
-    hipLaunchKernelGGL(weights_grad_kernel, dim3(n), dim3(SISR_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
-                       table_dev);
+extern "C" int sisr_weights_grad(const SisrWeightGradDesc* table_dev, int32_t n, float* dot_work, void* stream) {
+    if (!table_dev || n <= 0 || !dot_work) return SISR_E_BADARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(weights_grad_dot_kernel, dim3(n, WG_PARTS), dim3(SISR_BLOCK), 0, st, table_dev, dot_work);
+    SISR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(weights_grad_kernel, dim3(n, WG_PARTS), dim3(SISR_BLOCK), 0, st, table_dev, dot_work);
     SISR_CHECK_LAUNCH();
     return 0;
 }

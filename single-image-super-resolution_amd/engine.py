@@ -259,9 +259,38 @@ def prepare_weights(items, training, need_dgrad=True):
     return out, (big, sm, tab_dev)
 
 
+_PIN_RING = {'buf': None, 'off': 0}
+_PIN_CAPTURE = {'buf': None, 'off': 0}   # bump allocator for tables referenced by captured graphs
+_PIN_KEEP = []                           # ... whose pinned storage must outlive every replay
+
+
 def _table_to_device(table, dev):
-    host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
-    return host.to(dev, non_blocking=False)
+    """Descriptor table -> device without a host synchronisation: staged in pinned memory and copied
+    asynchronously on the current stream.  Eager mode uses a 4 MB pinned ring (a slot is reused only
+    thousands of launches later); under HIP-graph capture every table gets its own pinned buffer that is
+    kept alive forever, because the captured copy node re-reads it on each replay."""
+    raw = bytes(table)
+    n = (len(raw) + 255) & ~255
+    if torch.cuda.is_current_stream_capturing():
+        cap = _PIN_CAPTURE
+        if cap['buf'] is None or cap['off'] + n > cap['buf'].numel():
+            cap['buf'] = torch.empty(max(n, 1 << 20), dtype=torch.uint8, pin_memory=True)
+            cap['off'] = 0
+            _PIN_KEEP.append(cap['buf'])
+        host = cap['buf'][cap['off']:cap['off'] + n]
+        cap['off'] += n
+    else:
+        ring = _PIN_RING
+        if ring['buf'] is None:
+            ring['buf'] = torch.empty(4 << 20, dtype=torch.uint8, pin_memory=True)
+            _PIN_CAPTURE['buf'] = torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True)   # allocated OUTSIDE capture
+            _PIN_KEEP.append(_PIN_CAPTURE['buf'])
+        if ring['off'] + n > ring['buf'].numel():
+            ring['off'] = 0
+        host = ring['buf'][ring['off']:ring['off'] + n]
+        ring['off'] += n
+    host[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+    return host.to(dev, non_blocking=True)
 
 
 def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, res=None, out=None):
@@ -387,8 +416,10 @@ class WeightGradBatch:
             t.layout = 1 if p.kinds[2] else 0
             res[id(p.ref)] = (gw, gb)
         tab = _table_to_device(table, dev)
-        L.check(lib.sisr_weights_grad(tab.data_ptr(), len(self.items), _stream()), 'sisr_weights_grad')
-        self._keep = tab
+        work = torch.empty((16 * len(self.items),), dtype=torch.float32, device=dev)
+        L.check(lib.sisr_weights_grad(tab.data_ptr(), len(self.items), work.data_ptr(), _stream()),
+                'sisr_weights_grad')
+        self._keep = (tab, work)
         return res
 
 
