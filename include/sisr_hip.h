@@ -56,7 +56,9 @@ typedef struct SisrConvPlan {
     int32_t CK, PS, KROWP, n_chunk, CoutPad;
     int32_t msub, nsub;             /* 32x32 MFMA sub-tiles per wave (M) / per block (N)     */
     int32_t lds_bytes;
-    int32_t wpk_elems;              /* floats in the packed weight buffer                    */
+    int32_t wpk_elems;              /* elements in the packed weight buffer                  */
+    int32_t variant;                /* bf16 family: 0 generic (chunks of 32), 1 persistent
+                                       weights-resident kernel for Cin = 64 (one chunk of 64)  */
 } SisrConvPlan;
 
 /* Direct convolution, fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32) accumulate.
@@ -151,9 +153,10 @@ typedef struct SisrWeightDesc {
     float *wpk_dcls[4];
     int32_t c_KH[4], c_KW[4], c_R0y[4], c_R0x[4];
     int32_t c_CK[4], c_PS[4], c_KROWP[4], c_n_chunk[4], c_CoutPad[4];
-    /* bf16 images for the bf16-MFMA kernels: [chunk of 32 in-channels][cout][tap*32 + ci] (or NULL) */
+    /* bf16 images for the bf16-MFMA kernels: [chunk of CK in-channels][cout][tap*CK + ci] (or NULL) */
     void *wbf_fwd, *wbf_dgrad;
     int32_t bf_f_CoutPad, bf_d_CoutPad;
+    int32_t bf_f_CK, bf_d_CK;   /* in-channel chunk of the bf16 images: 32 (generic) or 64 (persistent kernel) */
 } SisrWeightDesc;
 
 int sisr_weights_prepare(const SisrWeightDesc *table_dev, int32_t n, void *stream);

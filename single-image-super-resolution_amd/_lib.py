@@ -26,7 +26,7 @@ _f32 = C.c_float
 class ConvPlan(C.Structure):
     _fields_ = [(n, _i32) for n in (
         'TH', 'TW', 'TN', 'tiles_y', 'tiles_x', 'n_groups', 'n_tiles', 'CK', 'PS', 'KROWP', 'n_chunk',
-        'CoutPad', 'msub', 'nsub', 'lds_bytes', 'wpk_elems')]
+        'CoutPad', 'msub', 'nsub', 'lds_bytes', 'wpk_elems', 'variant')]
 
 
 class ConvDesc(C.Structure):
@@ -61,7 +61,8 @@ class WeightDesc(C.Structure):
                 [('wpk_dcls', _f * 4)] +
                 [(n, _i32 * 4) for n in ('c_KH', 'c_KW', 'c_R0y', 'c_R0x', 'c_CK', 'c_PS', 'c_KROWP',
                                          'c_n_chunk', 'c_CoutPad')] +
-                [('wbf_fwd', _f), ('wbf_dgrad', _f), ('bf_f_CoutPad', _i32), ('bf_d_CoutPad', _i32)])
+                [('wbf_fwd', _f), ('wbf_dgrad', _f), ('bf_f_CoutPad', _i32), ('bf_d_CoutPad', _i32),
+                 ('bf_f_CK', _i32), ('bf_d_CK', _i32)])
 
 
 class WeightGradDesc(C.Structure):

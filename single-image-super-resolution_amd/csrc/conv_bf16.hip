@@ -15,6 +15,7 @@
 #include "sisr_dev.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "sisr_bf16_stage.h"
@@ -127,11 +128,23 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
     for (int chunk = 0; chunk < p.n_chunk; ++chunk) {
         __syncthreads();   // all fragment reads of the previous chunk are done
         stage_operand_tile_bf16(ov, lds_in, BF_PS, BF_CK, chunk * BF_CK, p.TN, IH, IW, n0, iy_org, ix_org, 1 << 30);
-        {   // packed weights of this chunk: [BN][WSG] contiguous bf16 -> LDS [BN][WS]
+        {   // packed weights of this chunk: [BN][WSG] contiguous bf16 -> LDS [BN][WS]; the 16-byte loads of
+            // a thread are issued in batches before the first LDS write (no load->write->load latency chain)
             const bf16x8* src = reinterpret_cast<const bf16x8*>(wsrc0 + ((int64_t)chunk * p.CoutPad + cout_base) * WSG);
-            for (int v = tid; v < wvecs; v += SISR_BLOCK) {
-                const int j = v / wvec_row, k8 = v - j * wvec_row;
-                *reinterpret_cast<bf16x8*>(lds_w + j * WS + k8 * 8) = src[v];
+            constexpr int WB = 5;
+            for (int v0 = tid; v0 < wvecs; v0 += WB * SISR_BLOCK) {
+                bf16x8 wv[WB];
+#pragma unroll
+                for (int u = 0; u < WB; ++u)
+                    if (v0 + u * SISR_BLOCK < wvecs) wv[u] = src[v0 + u * SISR_BLOCK];
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int v = v0 + u * SISR_BLOCK;
+                    if (v < wvecs) {
+                        const int j = v / wvec_row, k8 = v - j * wvec_row;
+                        *reinterpret_cast<bf16x8*>(lds_w + j * WS + k8 * 8) = wv[u];
+                    }
+                }
             }
         }
         __syncthreads();
@@ -250,7 +263,12 @@ static int conv_bf16_lds_bytes(int BM, int TN, int TH, int TW, int S, int KH, in
     return BM * 4 + in_elems * 2 + w_bytes + 16;
 }
 
+extern "C" int sisr_conv2d_plan_bf16_persist(SisrConvDesc* d);
+extern "C" int sisr_conv2d_bf16_persist(const SisrConvDesc* d, void* stream);
+
 extern "C" int sisr_conv2d_plan_bf16(SisrConvDesc* d) {
+    // Cin = 64, stride 1: experimental persistent weights-resident kernel, opt-in (SISR_BF16_PERSIST=1)
+    if (d && getenv("SISR_BF16_PERSIST") && sisr_conv2d_plan_bf16_persist(d) == 0) return 0;
     if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0) return SISR_E_BADARG;
     if ((d->Cin % BF_CK) || d->KH * d->KW > 9) return SISR_E_UNSUPPORTED;
     if (d->stride != 1 && d->stride != 2) return SISR_E_BADARG;
@@ -324,6 +342,7 @@ static int launch_conv_bf16(const SisrConvDesc* d, hipStream_t st) {
 
 extern "C" int sisr_conv2d_bf16(const SisrConvDesc* d, void* stream) {
     if (!d || !d->x1 || !d->wpk || !d->y) return SISR_E_BADARG;
+    if (d->plan.variant == 1) return sisr_conv2d_bf16_persist(d, stream);
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
     if (d->stat_part && (!d->cnt_part || d->y_mode != SISR_Y_NHWC)) return SISR_E_BADARG;
     const SisrConvPlan& p = d->plan;

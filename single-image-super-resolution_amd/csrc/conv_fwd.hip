@@ -130,10 +130,21 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_f32_kernel(const Sisr
                     d.wpk + ((int64_t)(chunk * d.KH + r) * p.CoutPad + cout_base) * p.KROWP);
                 const int k4 = tid & ((1 << wlg) - 1);
                 if (k4 < kr4) {
-                    for (int j = tid >> wlg; j < BN; j += SISR_BLOCK >> wlg) {
-                        const f32x4 v = src[j * kr4 + k4];
-                        float* dst = lds_w + j * WSTR + k4 * 4;
-                        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+                    constexpr int WB = 8;                  // loads in flight per thread
+                    const int jstep = SISR_BLOCK >> wlg;
+                    for (int j0 = tid >> wlg; j0 < BN; j0 += WB * jstep) {
+                        f32x4 wv[WB];
+#pragma unroll
+                        for (int u = 0; u < WB; ++u)
+                            if (j0 + u * jstep < BN) wv[u] = src[(j0 + u * jstep) * kr4 + k4];
+#pragma unroll
+                        for (int u = 0; u < WB; ++u) {
+                            const int j = j0 + u * jstep;
+                            if (j < BN) {
+                                float* dst = lds_w + j * WSTR + k4 * 4;
+                                dst[0] = wv[u][0]; dst[1] = wv[u][1]; dst[2] = wv[u][2]; dst[3] = wv[u][3];
+                            }
+                        }
                     }
                 }
             }

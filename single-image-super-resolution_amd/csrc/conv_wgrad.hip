@@ -89,10 +89,10 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_f32_kernel(const Sis
         const int tyi = tt_ % d.tiles_y, ng = tt_ / d.tiles_y;
         const int n0 = ng * d.TN, oy0 = tyi * d.TH, ox0 = txi * d.TW;
         __syncthreads();   // previous tile fully consumed
-        stage_operand_tile(ox, lds_in, d.PS, d.CK, q * d.CK, d.TN, IH, IW, n0, oy0 * S - d.pad_y,
+        stage_operand_tile<4>(ox, lds_in, d.PS, d.CK, q * d.CK, d.TN, IH, IW, n0, oy0 * S - d.pad_y,
                            ox0 * S - d.pad_x, xvec, 1 << 30, 64);
         // dy tile: TN x TH x TWp pixels, channels [co_base, co_base + DSTR); columns >= TW are zero
-        stage_operand_tile(og, lds_dy, DSTR, DSTR, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, gvec, d.TW, 0);
+        stage_operand_tile<4>(og, lds_dy, DSTR, DSTR, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, gvec, d.TW, 0);
         __syncthreads();
         if (d.bias_slab != nullptr && q == 0 && tid < DSTR) {
             const int npx = d.TN * d.TH * TWp;

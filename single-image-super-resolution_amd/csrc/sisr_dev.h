@@ -109,17 +109,17 @@ __device__ __forceinline__ f32x4 apply4(const f32x4 a, const f32x4 b, const f32x
     return v;
 }
 
-template <int PRO>
+template <int PRO, int SBQ>
 __device__ __forceinline__ void stage_tile_vec(const OperandView& o, float* lds, int PS, int CK, int c0,
                                                int TN, int IH, int IW, int n0, int iy_org, int ix_org,
                                                int valid_w) {
     constexpr bool need2 = PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD || PRO == SISR_PRO_ACT_BWD ||
                            PRO == SISR_PRO_TANH_BWD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int G = CK >> 2;
     int lg = 0;
     while ((1 << lg) < G) ++lg;
-    const int g = lane & (G - 1);
+    const int g = tid & (G - 1);
     const int c = c0 + g * 4;
     const bool c_ok = c < o.C;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -143,27 +143,44 @@ __device__ __forceinline__ void stage_tile_vec(const OperandView& o, float* lds,
         coff = c - ij * Cq; ysh = ij >> 1; xsh = ij & 1; Cp = Cq; Wp = 2 * o.W; Hp = 2 * o.H; mul = 2;
     }
     const int xstep = mul * Cp;
-    const int row_items = IW << lg;
-    for (int row = wave; row < TN * IH; row += SISR_BLOCK / 64) {
-        const int tn = row / IH, iyl = row - tn * IH;
-        const int n = n0 + tn, iy = iy_org + iyl;
-        const bool row_ok = c_ok && n < o.N && iy >= 0 && iy < o.H;
-        const int rbase = ((n * Hp + iy * mul + ysh) * Wp + xsh) * Cp + coff;
-        float* lrow = lds + row * IW * PS;
-        for (int item = lane; item < row_items; item += 64) {
-            const int ixl = item >> lg;
-            const int ix = ix_org + ixl;
-            f32x4 v = zero;
-            if (row_ok && ix >= 0 && ix < o.W && ixl < valid_w) {
-                const int off = rbase + ix * xstep;
-                const f32x4 a = *reinterpret_cast<const f32x4*>(o.x1 + off);
-                f32x4 b = zero;
-                if (need2) b = *reinterpret_cast<const f32x4*>(o.x2 + off);
-                v = apply4<PRO>(a, b, ka, kb, kd, ks, kt, o.slope);
+    // flat item loop with batched loads (see sisr_bf16_stage.h): ~one memory latency per tile
+    constexpr int SB = need2 ? SBQ / 2 : SBQ;      // loads in flight per thread and operand
+    const int ppi = SISR_BLOCK >> lg;
+    const int step_rows = ppi / IW, step_cols = ppi - step_rows * IW;
+    const int rows = TN * IH, npix = rows * IW;
+    int pix = tid >> lg;
+    int row = pix / IW, ixl = pix - row * IW;
+    for (; pix < npix; ) {
+        f32x4 a[SB], b[need2 ? SB : 1];
+        int lds_off[SB];
+        bool live[SB], ok[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            live[u] = pix < npix;
+            int tn = 0, iyl = row;
+            if (TN > 1) { tn = row / IH; iyl = row - tn * IH; }
+            const int n = n0 + tn, iy = iy_org + iyl, ix = ix_org + ixl;
+            ok[u] = live[u] && c_ok && n < o.N && iy >= 0 && iy < o.H && ix >= 0 && ix < o.W && ixl < valid_w;
+            lds_off[u] = pix * PS + g * 4;
+            a[u] = zero;
+            if (need2) b[u] = zero;
+            if (ok[u]) {
+                const int off = ((n * Hp + iy * mul + ysh) * Wp + xsh) * Cp + coff + ix * xstep;
+                a[u] = *reinterpret_cast<const f32x4*>(o.x1 + off);
+                if (need2) b[u] = *reinterpret_cast<const f32x4*>(o.x2 + off);
             }
-            float* dst = lrow + ixl * PS + g * 4;
-            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
-            if (g == 0 && PS > CK) lrow[ixl * PS + CK] = 0.f;
+            pix += ppi; row += step_rows; ixl += step_cols;
+            if (ixl >= IW) { ixl -= IW; ++row; }
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            if (live[u]) {
+                f32x4 v = zero;
+                if (ok[u]) v = apply4<PRO>(a[u], need2 ? b[u] : zero, ka, kb, kd, ks, kt, o.slope);
+                float* dst = lds + lds_off[u];
+                dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+                if (g == 0 && PS > CK) lds[lds_off[u] + CK] = 0.f;
+            }
         }
     }
 }
@@ -173,6 +190,7 @@ __device__ __forceinline__ void stage_tile_vec(const OperandView& o, float* lds,
 // outside the image and channel slots >= CK (the pad slot) are written as 0.
 //   tile pixels: TN x IH x IW, origin image n0, input row iy_org, col ix_org; tile columns
 //   >= valid_w are forced to 0; `slack` (<= 64) extra floats after the tile are zeroed.
+template <int SBQ = 8>
 __device__ __forceinline__ void stage_operand_tile(const OperandView& o, float* lds, int PS, int CK,
                                                    int c0, int TN, int IH, int IW, int n0, int iy_org,
                                                    int ix_org, bool vec_ok, int valid_w, int slack) {
@@ -181,7 +199,7 @@ __device__ __forceinline__ void stage_operand_tile(const OperandView& o, float* 
     if (vec_ok) {
         switch (o.pro) {
 #define SISR_STAGE_CASE(P) \
-    case P: stage_tile_vec<P>(o, lds, PS, CK, c0, TN, IH, IW, n0, iy_org, ix_org, valid_w); break;
+    case P: stage_tile_vec<P, SBQ>(o, lds, PS, CK, c0, TN, IH, IW, n0, iy_org, ix_org, valid_w); break;
             SISR_STAGE_CASE(SISR_PRO_NONE)
             SISR_STAGE_CASE(SISR_PRO_ACT)
             SISR_STAGE_CASE(SISR_PRO_AFFINE_ACT)
@@ -192,22 +210,33 @@ __device__ __forceinline__ void stage_operand_tile(const OperandView& o, float* 
 #undef SISR_STAGE_CASE
         }
     } else {
+        // scalar path (NCHW images, 1/3/4/16-channel layers): only the VALID channels of the chunk are
+        // fetched -- items = pixels x valid channels, pixel index fastest for NCHW so the loads coalesce --
+        // the remaining slots of each pixel are zero-filled by a cheap second loop.
         const bool need2 = operand_needs_x2(o.pro);
-        const int items = npix * PS;
-        for (int it = tid; it < items; it += SISR_BLOCK) {
-            const int pix = it / PS, cs = it - pix * PS;
-            const int tn = pix / (IH * IW), rem = pix - tn * (IH * IW);
+        const int cv = max(0, min(CK, o.C - c0));          // valid channels in this chunk
+        const int hw = IH * IW;
+        for (int it = tid; it < npix * cv; it += SISR_BLOCK) {
+            int pix, cs;
+            if (o.mode == SISR_X_NCHW) { cs = it / npix; pix = it - cs * npix; }
+            else { pix = it / cv; cs = it - pix * cv; }
+            const int tn = pix / hw, rem = pix - tn * hw;
             const int iyl = rem / IW, ixl = rem - iyl * IW;
             const int n = n0 + tn, iy = iy_org + iyl, ix = ix_org + ixl;
             const int c = c0 + cs;
             float v = 0.f;
-            if (cs < CK && c < o.C && n < o.N && iy >= 0 && iy < o.H && ix >= 0 && ix < o.W && ixl < valid_w) {
+            if (n < o.N && iy >= 0 && iy < o.H && ix >= 0 && ix < o.W && ixl < valid_w) {
                 const int64_t off = operand_offset(o, n, iy, ix, c);
                 const float a = o.x1[off];
                 const float b = need2 ? o.x2[off] : 0.f;
                 v = operand_apply(o, a, b, c);
             }
-            lds[it] = v;
+            lds[pix * PS + cs] = v;
+        }
+        const int pad = PS - cv;
+        for (int it = tid; it < npix * pad; it += SISR_BLOCK) {
+            const int pix = it / pad, cs = cv + (it - pix * pad);
+            lds[pix * PS + cs] = 0.f;
         }
     }
     if (tid < slack) lds[npix * PS + tid] = 0.f;   // slack read by zero-weight / masked K tails

@@ -128,15 +128,16 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
     // bf16 images for conv_bf16.hip: [chunk32][cp][tap*32 + cl]
     if (w.wbf_fwd) {
         __bf16* dst = reinterpret_cast<__bf16*>(w.wbf_fwd);
-        const int taps = w.KH * w.KW, WSG = taps * 32;
-        const int64_t total = (int64_t)(w.Cin / 32) * w.bf_f_CoutPad * WSG;
+        const int CKb = w.bf_f_CK;
+        const int taps = w.KH * w.KW, WSG = taps * CKb;
+        const int64_t total = (int64_t)(w.Cin / CKb) * w.bf_f_CoutPad * WSG;
         for (int64_t e = start; e < total; e += stride) {
             int64_t tq = e;
             const int kidx = (int)(tq % WSG); tq /= WSG;
             const int cp = (int)(tq % w.bf_f_CoutPad);
             const int chunk = (int)(tq / w.bf_f_CoutPad);
-            const int tap = kidx >> 5, cl = kidx & 31;
-            const int r = tap / w.KW, sx = tap - r * w.KW, ci = chunk * 32 + cl;
+            const int tap = kidx / CKb, cl = kidx - tap * CKb;
+            const int r = tap / w.KW, sx = tap - r * w.KW, ci = chunk * CKb + cl;
             float val = 0.f;
             if (cp < w.Cout) {
                 const int co = unpermute_cout(cp, w.Cout, w.shuffle2);
@@ -147,15 +148,16 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
     }
     if (w.wbf_dgrad) {
         __bf16* dst = reinterpret_cast<__bf16*>(w.wbf_dgrad);
-        const int taps = w.KH * w.KW, WSG = taps * 32;
-        const int64_t total = (int64_t)(w.Cout / 32) * w.bf_d_CoutPad * WSG;
+        const int CKb = w.bf_d_CK;
+        const int taps = w.KH * w.KW, WSG = taps * CKb;
+        const int64_t total = (int64_t)(w.Cout / CKb) * w.bf_d_CoutPad * WSG;
         for (int64_t e = start; e < total; e += stride) {
             int64_t tq = e;
             const int kidx = (int)(tq % WSG); tq /= WSG;
             const int op = (int)(tq % w.bf_d_CoutPad);
             const int chunk = (int)(tq / w.bf_d_CoutPad);
-            const int tap = kidx >> 5, il = kidx & 31;
-            const int r = tap / w.KW, sx = tap - r * w.KW, ip = chunk * 32 + il;
+            const int tap = kidx / CKb, il = kidx - tap * CKb;
+            const int r = tap / w.KW, sx = tap - r * w.KW, ip = chunk * CKb + il;
             float val = 0.f;
             if (op < w.Cin) {
                 const int co = unpermute_cout(ip, w.Cout, w.shuffle2);

@@ -81,9 +81,9 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
         const int tyi = tt_ % d.tiles_y, ng = tt_ / d.tiles_y;
         const int n0 = ng * d.TN, oy0 = tyi * d.TH, ox0 = txi * d.TW;
         __syncthreads();   // previous tile fully consumed
-        stage_operand_tile_bf16(ox, lds_in, BF_PS, BF_CK, q * BF_CK, d.TN, IH, IW, n0, oy0 * S - d.pad_y,
+        stage_operand_tile_bf16<4>(ox, lds_in, BF_PS, BF_CK, q * BF_CK, d.TN, IH, IW, n0, oy0 * S - d.pad_y,
                                 ox0 * S - d.pad_x, 1 << 30);
-        stage_operand_tile_bf16(og, lds_dy, DS, DCH, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, d.TW);
+        stage_operand_tile_bf16<4>(og, lds_dy, DS, DCH, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, d.TW);
         __syncthreads();
         if (d.bias_slab != nullptr && q == 0 && tid < DCH) {
             const int npx = d.TN * d.TH * TWp;

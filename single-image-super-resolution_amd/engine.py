@@ -221,11 +221,11 @@ def prepare_weights(items, training, need_dgrad=True):
         t.w_orig = ref.weight.data_ptr()
         t.sigma = p.sigma.data_ptr()
         if kinds[0]:
-            t.wbf_fwd, t.bf_f_CoutPad = p.wpk_fwd.data_ptr(), f.plan.CoutPad
+            t.wbf_fwd, t.bf_f_CoutPad, t.bf_f_CK = p.wpk_fwd.data_ptr(), f.plan.CoutPad, f.plan.CK
         else:
             t.wpk_fwd = p.wpk_fwd.data_ptr()
         if kinds[1]:
-            t.wbf_dgrad, t.bf_d_CoutPad = p.wpk_dgrad.data_ptr(), d.plan.CoutPad
+            t.wbf_dgrad, t.bf_d_CoutPad, t.bf_d_CK = p.wpk_dgrad.data_ptr(), d.plan.CoutPad, d.plan.CK
         else:
             t.wpk_dgrad = None if isinstance(p.wpk_dgrad, list) else _ptr(p.wpk_dgrad)
         t.Cout, t.Cin, t.KH, t.KW = gm.cout, gm.cin, gm.k, gm.k
