@@ -234,23 +234,40 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
         if (tid == 0 && blockIdx.y == 0) d.cnt_part[blockIdx.x] = cnt;
     }
 
+    // residual / tanh flags are wave-uniform: hoisted out of the per-element loops
+    int ro[MSUB][16];
 #pragma unroll
     for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = wave * (MSUB * 32) + ms * 32 + mfma_row(i, lane);
-            const int ro = row_off[row];
-            if (ro < 0) continue;
+        for (int i = 0; i < 16; ++i) ro[ms][i] = row_off[wave * (MSUB * 32) + ms * 32 + mfma_row(i, lane)];
+    if (d.res != nullptr) {
 #pragma unroll
-            for (int ns = 0; ns < NSUB; ++ns) {
-                if (!col_ok[ns]) continue;
-                const int64_t off = (int64_t)ro + col_off[ns];
-                float v = acc[ms][ns][i];
-                if (d.res != nullptr) v += d.res[off];
-                if (d.epi_act == SISR_EPI_TANH) v = tanhf(v);
-                d.y[off] = v;
+        for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (ro[ms][i] >= 0) {
+#pragma unroll
+                    for (int ns = 0; ns < NSUB; ++ns)
+                        if (col_ok[ns]) acc[ms][ns][i] += d.res[(int64_t)ro[ms][i] + col_off[ns]];
+                }
+    }
+    if (d.epi_act == SISR_EPI_TANH) {
+#pragma unroll
+        for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[ms][ns][i] = tanhf(acc[ms][ns][i]);
+    }
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (ro[ms][i] >= 0) {
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns)
+                    if (col_ok[ns]) d.y[(int64_t)ro[ms][i] + col_off[ns]] = acc[ms][ns][i];
             }
-        }
 }
 
 // ---- host ------------------------------------------------------------------------------------------

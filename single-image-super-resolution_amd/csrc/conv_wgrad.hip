@@ -94,10 +94,14 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_f32_kernel(const Sis
         // dy tile: TN x TH x TWp pixels, channels [co_base, co_base + DSTR); columns >= TW are zero
         stage_operand_tile<4>(og, lds_dy, DSTR, DSTR, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, gvec, d.TW, 0);
         __syncthreads();
-        if (d.bias_slab != nullptr && q == 0 && tid < DSTR) {
+        if (d.bias_slab != nullptr && q == 0) {
+            // bias-gradient partial: every thread sums a strided share of the tile's pixels for one channel
+            // (all 256 threads, independent loads) -- combined across the pixel shares after the tile loop
+            const int co = tid % DSTR, share = tid / DSTR, nshare = SISR_BLOCK / DSTR;
             const int npx = d.TN * d.TH * TWp;
             float s = 0.f;
-            for (int px = 0; px < npx; ++px) s += lds_dy[px * DSTR + tid];
+#pragma unroll 8
+            for (int px = share; px < npx; px += nshare) s += lds_dy[px * DSTR + co];
             bias_acc += s;
         }
         const int nrows = d.TN * d.TH;
@@ -149,8 +153,17 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_f32_kernel(const Sis
             }
         }
     }
-    if (d.bias_slab != nullptr && q == 0 && tid < DSTR)
-        d.bias_slab[(int64_t)blockIdx.x * d.slab_stride + co_base + tid] = bias_acc;
+    if (d.bias_slab != nullptr && q == 0) {
+        __syncthreads();                                   // LDS is free: all tiles and the part reduction are done
+        float* bsh = smem;
+        bsh[tid] = bias_acc;
+        __syncthreads();
+        if (tid < DSTR) {
+            float s = 0.f;
+            for (int k = tid; k < SISR_BLOCK; k += DSTR) s += bsh[k];
+            d.bias_slab[(int64_t)blockIdx.x * d.slab_stride + co_base + tid] = s;
+        }
+    }
 }
 
 // out[i] = sum_k slab[k][i]: 64 float4 columns x 4 slab-splits per workgroup, combined through LDS

@@ -85,10 +85,14 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
                                 ox0 * S - d.pad_x, 1 << 30);
         stage_operand_tile_bf16<4>(og, lds_dy, DS, DCH, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, d.TW);
         __syncthreads();
-        if (d.bias_slab != nullptr && q == 0 && tid < DCH) {
+        if (d.bias_slab != nullptr && q == 0) {
+            // bias-gradient partial: every thread sums a strided share of the tile's pixels for one channel
+            // (all 256 threads, independent loads) -- combined across the pixel shares after the tile loop
+            const int co = tid % DCH, share = tid / DCH, nshare = SISR_BLOCK / DCH;
             const int npx = d.TN * d.TH * TWp;
             float s = 0.f;
-            for (int px = 0; px < npx; ++px) s += (float)lds_dy[px * DS + tid];
+#pragma unroll 8
+            for (int px = share; px < npx; px += nshare) s += (float)lds_dy[px * DS + co];
             bias_acc += s;
         }
         const int nrows = d.TN * d.TH;
@@ -156,8 +160,17 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
                 sl[((int64_t)(q * NTAP + a) * 32 + ci) * d.CoutPad + co_base + jsub * 32 + (lane & 31)] = acc[a][i];
             }
     }
-    if (d.bias_slab != nullptr && q == 0 && tid < DCH)
-        d.bias_slab[(int64_t)blockIdx.x * d.slab_stride + co_base + tid] = bias_acc;
+    if (d.bias_slab != nullptr && q == 0) {
+        __syncthreads();                                   // LDS is free: all tiles and the part reduction are done
+        float* bsh = smem;
+        bsh[tid] = bias_acc;
+        __syncthreads();
+        if (tid < DCH) {
+            float s = 0.f;
+            for (int k = tid; k < SISR_BLOCK; k += DCH) s += bsh[k];
+            d.bias_slab[(int64_t)blockIdx.x * d.slab_stride + co_base + tid] = s;
+        }
+    }
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
