@@ -333,7 +333,11 @@ extern "C" int sisr_conv2d_plan_bf16(SisrConvDesc* d) {
         cand_lds[mi] = best_lds;
         cand_cost[mi] = (double)((blocks + 511) / 512) * BM * (mi == 0 ? 1.0 : 1.05);
     }
-    const int pick = cand_cost[1] < cand_cost[0] ? 1 : 0;
+    int pick = cand_cost[1] < cand_cost[0] ? 1 : 0;
+    if (const char* e = getenv("SISR_BF16_MSUB")) {          // A/B override of the workgroup height
+        const int want = atoi(e) == 2 ? 0 : 1;
+        if (cand_cost[want] < 1e29) pick = want;
+    }
     if (cand_cost[pick] > 1e29) return SISR_E_TOOBIG;
     p = cand[pick];
     p.n_tiles = p.tiles_y * p.tiles_x * p.n_groups;
