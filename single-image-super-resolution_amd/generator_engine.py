@@ -55,11 +55,13 @@ class Saved:
 
 
 def run_forward(topo, x, training):
-    """x: NCHW fp32 device tensor.  Returns (out NCHW, Saved)."""
+    """x: NCHW fp32 device tensor.  Returns (out NCHW, Saved).  With ``topo.end is None`` the schedule stops
+    before the final conv+tanh (``forward_no_end``, model_generator.py:86-96) and returns the activated
+    upscale output as an NCHW tensor."""
     E.require_gpu_tensor(x, 'generator input')
     x = x.contiguous()
     n, cimg, h, w = x.shape
-    refs = topo.conv_refs()
+    refs = [r for r in topo.conv_refs() if r is not None]
     items = [(topo.first, n, h, w)]
     for b in topo.blocks:
         items += [(b['c1'], n, h, w), (b['c2'], n, h, w)]
@@ -68,7 +70,8 @@ def run_forward(topo, x, training):
     for ref, _ in topo.stages:
         items.append((ref, n, hh, ww))
         hh, ww = hh * 2, ww * 2
-    items.append((topo.end, n, hh, ww))
+    if topo.end is not None:
+        items.append((topo.end, n, hh, ww))
     preps, keep = E.prepare_weights(items, training)
     P = {id(r): p for r, p in zip(refs, preps)}
     sv = Saved()
@@ -112,7 +115,12 @@ def run_forward(topo, x, training):
         sv.stage_pre.append(pre)
         cur = Operand.act(pre, slope)
     sv.end_in = cur
-    out, _, _ = E.conv_forward(P[id(topo.end)], cur, bias=topo.end.bias, y_mode=L.Y_NCHW, epi=L.EPI_TANH)
+    if topo.end is None:            # forward_no_end: materialise the (lazy) activation in the reference's NCHW layout
+        nn_, hh_, ww_, cc_ = cur.dims
+        out = torch.empty((nn_, cc_, hh_, ww_), dtype=torch.float32, device=x.device)
+        E.nhwc_to_nchw(cur.x1, out, cc_ * hh_ * ww_, cur.pa, cur.pd, cur.slope if cur.pro != L.PRO_NONE else None)
+    else:
+        out, _, _ = E.conv_forward(P[id(topo.end)], cur, bias=topo.end.bias, y_mode=L.Y_NCHW, epi=L.EPI_TANH)
     sv.out = out
     if training:
         torch._foreach_add_([m.num_batches_tracked for m in topo.bn_modules()], 1)
@@ -138,10 +146,15 @@ def run_backward(sv, grad_out, need_dx):
         return E.conv_dgrad(p, dy_op, res=res, y_mode=y_mode) if need_dgrad else None
 
     n = sv.x.shape[0]
-    # ---- end conv + tanh ---------------------------------------------------------------------------
+    # ---- end conv + tanh (or, for forward_no_end, the NCHW -> NHWC change of the incoming gradient) --------
     ho, wo = sv.out.shape[2], sv.out.shape[3]
-    dy = Operand(grad_out, (n, ho, wo, sv.out.shape[1]), pro=L.PRO_TANH_BWD, mode=L.X_NCHW, x2=sv.out)
-    g = conv_bwd(topo.end, sv.end_in, dy)                  # grad wrt the (activated) input of `end`
+    if topo.end is None:
+        if not topo.stages:
+            raise NotImplementedError('backward of forward_no_end without an upscale stage')
+        g = E.nchw_to_nhwc(grad_out, sv.out.shape[1] * ho * wo, n, ho, wo, sv.out.shape[1])
+    else:
+        dy = Operand(grad_out, (n, ho, wo, sv.out.shape[1]), pro=L.PRO_TANH_BWD, mode=L.X_NCHW, x2=sv.out)
+        g = conv_bwd(topo.end, sv.end_in, dy)              # grad wrt the (activated) input of `end`
     # ---- upscale stages, last to first ---------------------------------------------------------------
     for k in range(len(topo.stages) - 1, -1, -1):
         ref, slope = topo.stages[k]
@@ -181,7 +194,7 @@ def run_backward(sv, grad_out, need_dx):
     x_op = Operand.plain(sv.x, dims=(n, sv.x.shape[2], sv.x.shape[3], sv.x.shape[1]), mode=L.X_NCHW)
     gx = conv_bwd(topo.first, x_op, dy0, need_dgrad=need_dx, y_mode=L.Y_NCHW)
     for ref_id, (gw, gb) in wg.run().items():
-        ref = next(r for r in topo.conv_refs() if id(r) == ref_id)
+        ref = next(r for r in topo.conv_refs() if r is not None and id(r) == ref_id)
         if gw is not None:
             grads[id(ref.weight)] = gw
         if gb is not None:

@@ -95,8 +95,8 @@ class Generator(nn.Module):
         return self.end
 
     def forward_no_end(self, x):
-        raise NotImplementedError('forward_no_end as a standalone call is not exposed by the fused MI355X '
-                                  'path yet; GeneratorSuffix composes the prefix internally')
+        """model_generator.py:86-96: everything but ``end`` (NCHW activation after the last upscale stage)"""
+        return GE.generator_apply(self._topology(with_end=False), self, x)
 
     def forward(self, x):
         return GE.generator_apply(self._topology(), self, x)
@@ -131,8 +131,8 @@ class GeneratorSuffix(nn.Module):
         return t
 
     def forward_no_end(self, x):
-        raise NotImplementedError('forward_no_end as a standalone call is not exposed by the fused MI355X '
-                                  'path yet')
+        """model_generator.py:133-136"""
+        return GE.generator_apply(self._topology(with_end=False), self, x)
 
     def forward(self, x):
         return GE.generator_apply(self._topology(), self, x)

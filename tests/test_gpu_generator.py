@@ -90,3 +90,32 @@ def test_generator_bf16_mode_tracks_reference(name):
                 assert cos > 0.9, (k, cos)
     finally:
         E.set_precision('fp32')
+
+
+def test_forward_no_end_matches_oracle():
+    """Generator.forward_no_end / GeneratorSuffix.forward_no_end (model_generator.py:86-96,133-136): the
+    NCHW activation in front of `end`, with gradients, against the CPU oracle."""
+    from oracle import models as om, ops as oo
+    z, cfg, state, grads, after = load_case('gen_x4_suffix_w32')
+    net = build(cfg)
+    net.load_state_dict(state, strict=True)
+    net = net.cuda().train()
+    x = torch.from_numpy(z['x']).cuda().requires_grad_(True)
+    y = net.forward_no_end(x)
+    st = {k: v.clone() for k, v in state.items()}
+    for k in om.param_keys(st):
+        st[k].requires_grad_(True)
+    xr = torch.from_numpy(z['x']).clone().requires_grad_(True)
+    c = om._Ctx(st, True)
+    yr = om._gen_no_end(c, 'base.', xr, (2,))
+    yr = oo.prelu(oo.pixel_shuffle(c.conv('upscale.0', yr), 2), st['upscale.2.weight'])
+    assert tuple(y.shape) == tuple(yr.shape)
+    assert rel_err(y.detach().cpu(), yr.detach()) < TOL
+    r = torch.rand(yr.shape, generator=torch.Generator().manual_seed(3)) - 0.5
+    (yr * r).sum().backward()
+    (y * r.cuda()).sum().backward()
+    assert rel_err(x.grad.cpu(), xr.grad) < TOL
+    got = {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}
+    ref = {k: st[k].grad for k in got}
+    assert grads_close(got, ref, TOL) == []
+    assert all(p.grad is None for k, p in net.named_parameters() if k.startswith('base.end'))
