@@ -12,9 +12,10 @@
 // Merge of the per-tile (count, mean_b, M2_b) partials in two fully parallel passes (no serial chain):
 //   N = sum n_b ; mean = sum n_b*mean_b / N ; M2 = sum [ M2_b + n_b*(mean_b - mean)^2 ]
 // (algebraically Chan et al.'s pairwise update summed over all tiles; all sums in double).
-// Workgroup = 16 channels x 64 tile-splits (1024 threads).
-#define BNF_SPLITS 64
-__device__ __forceinline__ double bnf_reduce(double v, double (*sh)[16], int split, int cl) {
+// Workgroup = 4 channels x 256 tile-splits (1024 threads): C/4 workgroups, a few tiles per thread.
+#define BNF_SPLITS 256
+#define BNF_CH 4
+__device__ __forceinline__ double bnf_reduce(double v, double (*sh)[BNF_CH], int split, int cl) {
     sh[split][cl] = v;
     __syncthreads();
     for (int half = BNF_SPLITS / 2; half >= 1; half >>= 1) {
@@ -31,9 +32,9 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
     float* save_invstd) {
-    __shared__ double sh[BNF_SPLITS][16];
-    const int cl = threadIdx.x & 15, split = threadIdx.x >> 4;
-    const int c = min(blockIdx.x * 16 + cl, C - 1);
+    __shared__ double sh[BNF_SPLITS][BNF_CH];
+    const int cl = threadIdx.x & (BNF_CH - 1), split = threadIdx.x / BNF_CH;
+    const int c = min(blockIdx.x * BNF_CH + cl, C - 1);
     double n = 0.0, s = 0.0;
     for (int t = split; t < n_tiles; t += BNF_SPLITS) {
         const double nb = cnt_part[t];
@@ -49,7 +50,7 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(
         m2 += (double)stat_part[(int64_t)t * 2 * C + C + c] + nb * dm * dm;
     }
     m2 = bnf_reduce(m2, sh, split, cl);
-    if (split == 0 && blockIdx.x * 16 + cl < C) {
+    if (split == 0 && blockIdx.x * BNF_CH + cl < C) {
         const double var = m2 / n;                       // biased (normalisation)
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = gamma[c] * invstd;
@@ -220,7 +221,7 @@ extern "C" int sisr_bn_finalize(const float* stat_part, const float* cnt_part, i
     if (!stat_part || !cnt_part || n_tiles <= 0 || C <= 0 || !gamma || !beta || !running_mean || !running_var ||
         !scale || !shift || !save_mean || !save_invstd)
         return SISR_E_BADARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), stat_part,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BNF_CH - 1) / BNF_CH), dim3(1024), 0, S_(stream), stat_part,
                        cnt_part, n_tiles, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
                        save_mean, save_invstd);
     SISR_CHECK_LAUNCH();
