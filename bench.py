@@ -177,6 +177,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only for 1-GPU rehearsals)')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a HIP graph')
     ap.add_argument('--precision', choices=['bf16', 'fp32'], default=os.environ.get('SISR_PRECISION', 'bf16'),
                     help='bf16: bf16 matrix cores with fp32 accumulate (BASELINE config 1); fp32: exact-fp32 parity build')
@@ -186,11 +187,15 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    local = local % max(1, torch.cuda.device_count())           # rehearsal: several ranks may share one GPU (gloo)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)         # "nccl" is RCCL on ROCm
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)     # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
     sub('engine').set_precision(args.precision)
     step, net, capture = make_step(device, rank, world)
     graphed = False
