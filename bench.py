@@ -122,8 +122,17 @@ def dominant_kernel_roofline(device, precision, iters=40):
         # and the output tensor cross HBM once each; this round both are stored fp32): 2 * B*h*w*64 * 4 B
         nbytes = 2.0 * B * LR * LR * 64 * 4
         achieved = nbytes / (ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE, WRITE_SIZE): bench.py cannot run rocprofv3 on
+        # itself, so the figure collected for this kernel with separate --pmc passes (tools/prof_conv.py,
+        # gfx950 corrections applied) is committed under profiles/ and reported here; null if absent
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_traffic_trunk_conv.json')) as fh:
+                traffic = json.load(fh)['traffic_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
         return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / PEAK_HBM_GBS, 4), 'traffic': None,
+                'frac': round(achieved / PEAK_HBM_GBS, 4), 'traffic': traffic,
                 'kernel': 'conv_mfma_bf16_kernel<*,2,1> (3x3 64->64 trunk conv, fp32 tensors in HBM)',
                 'launch_ms': round(ms, 4), 'alg_bytes_per_launch': nbytes,
                 'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 1)}
