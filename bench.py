@@ -105,14 +105,13 @@ def dominant_kernel_roofline(device, precision, iters=40):
     slope = torch.full((1,), 0.25, device=device)
     op = E.Operand.affine_act(x, sc, sh, slope)
     out = torch.empty_like(x)
-    dbg = int(os.environ.get('SISR_DBG_EPI', '0'))        # timing-only ablation bits of the persistent kernel
     for _ in range(5):
-        E.conv_forward(preps[0], op, bias=bias, stats=True, out=out, epi=dbg)
+        E.conv_forward(preps[0], op, bias=bias, stats=True, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()                       # events on the current stream = the stream the kernel runs on
     for _ in range(iters):
-        E.conv_forward(preps[0], op, bias=bias, stats=True, out=out, epi=dbg)
+        E.conv_forward(preps[0], op, bias=bias, stats=True, out=out)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters

@@ -1,0 +1,84 @@
+"""GPU: the bf16 matrix-core mode (perf build) on the discriminator, MaskedVGG and a whole training
+iteration.  Layers with Cin % 32 == 0 round their MFMA operands to bf16 (fp32 accumulate); stride-2
+forward convs and the weight gradients use the bf16 kernels, stride-2 data gradients and 3-channel
+edge layers stay on the fp32 kernels.  Tolerances are bf16-sized (stated per assert); the 1e-3 parity
+bar belongs to the default fp32 build (tests/test_gpu_*.py)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_helpers import pkg
+from helpers import load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos(a, b):
+    return float(torch.nn.functional.cosine_similarity(a.reshape(1, -1).double(), b.reshape(1, -1).double()))
+
+
+@pytest.fixture()
+def bf16_engine():
+    E = pkg('engine')
+    E.set_precision('bf16')
+    yield E
+    E.set_precision('fp32')
+
+
+def test_discriminator_bf16_mode(bf16_engine):
+    z, cfg, state, grads, after = load_case('dis_16px_w16')
+    md = pkg('model_discriminator')
+    net = md.Discriminator(tuple(cfg['input_shape']), cfg['list_n_features'], cfg['list_stride'])
+    net.load_state_dict(state, strict=True)
+    net = net.cuda().train()
+    x = torch.from_numpy(z['x']).cuda().requires_grad_(True)
+    out = net(x)
+    assert rel_err(out.detach().cpu(), z['out']) < 3e-2
+    (out * torch.from_numpy(z['r']).cuda()).sum().backward()
+    assert _cos(x.grad.cpu(), torch.from_numpy(z['grad_x'])) > 0.98
+    big = max(float(v.abs().max()) for v in grads.values())
+    for k, p in net.named_parameters():
+        if grads[k].numel() >= 64 and float(grads[k].abs().max()) > 0.05 * big:
+            assert _cos(p.grad.cpu(), grads[k]) > 0.95, k
+
+
+def test_masked_vgg_bf16_mode(bf16_engine, golden_dir):
+    z = np.load(golden_dir + '/vgg_standin.npz')
+    mce = pkg('model_content_extractor')
+    div = int(z['width_div'])
+    state = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('state/')}
+    for mask in (0b00010, 0b01111, 0b10000):
+        net = mce.MaskedVGG(mask, width_div=div, pretrained=False)
+        net.load_state_dict({k: v for k, v in state.items() if k in net.state_dict()}, strict=True)
+        net = net.cuda()
+        x = torch.from_numpy(z['x']).cuda().requires_grad_(True)
+        f = net(x)
+        assert rel_err(f.detach().cpu(), z['out_%d' % mask]) < 3e-2, mask
+        (f * torch.from_numpy(z['r_%d' % mask]).cuda()).sum().backward()
+        # 16 bf16 layers deep with ReLU / max-pool masks that flip on rounding: direction, not digits
+        assert _cos(x.grad.cpu(), torch.from_numpy(z['grad_x_%d' % mask])) > (0.93 if mask >= 16 else 0.97), mask
+
+
+def test_training_iteration_runs_in_bf16_mode(bf16_engine):
+    """D step + G step with the full-width modules at HR 32 (shapes where every bf16 kernel family is
+    exercised: trunk, upscale with PixelShuffle, stride-2 forward, FC, VGG22) -- finite losses and grads."""
+    mg, md, mce, ut = pkg('model_generator'), pkg('model_discriminator'), pkg('model_content_extractor'), pkg('utils')
+    torch.manual_seed(0)
+    dev = torch.device('cuda')
+    net_g = mg.Generator(2, 64, 256, [2], use_sn=True).to(dev)
+    net_d = md.Discriminator((3, 32, 32), [64, 64, 128, 128], [1, 2, 1, 2]).to(dev)
+    ext = mce.MaskedVGG(0b00010, pretrained=False).to(dev)
+    crit = torch.nn.BCELoss()
+    hr = (torch.rand(8, 3, 32, 32, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(dev)
+    fake = net_g(ut.lr_from_hr(hr, (16, 16), device=dev))
+    net_d.zero_grad()
+    err_d = crit(net_d(hr).view(-1), torch.full((8,), .9, device=dev)) + \
+        crit(net_d(fake.detach()).view(-1), torch.zeros(8, device=dev))
+    err_d.backward()
+    net_g.zero_grad()
+    err_g = crit(net_d(fake).view(-1), torch.ones(8, device=dev)) * 5e-2 + torch.mean(torch.pow(ext(hr) - ext(fake), 2))
+    err_g.backward()
+    assert torch.isfinite(err_d) and torch.isfinite(err_g)
+    for net in (net_g, net_d):
+        for k, p in net.named_parameters():
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
