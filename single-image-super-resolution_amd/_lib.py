@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libsisr_hip.so')
+LIB_PATH = os.environ.get('SISR_LIB') or os.path.join(CSRC, 'libsisr_hip.so')      # SISR_LIB: developer builds
 
 # enums (sisr_hip.h)
 PRO_NONE, PRO_ACT, PRO_AFFINE_ACT, PRO_BNBWD, PRO_BNACT_BWD, PRO_ACT_BWD, PRO_TANH_BWD = range(7)

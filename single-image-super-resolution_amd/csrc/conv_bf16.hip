@@ -20,6 +20,24 @@
 
 #include "sisr_bf16_stage.h"
 
+// Phase timeline of the generic kernel (developer build only: `make trace` -> libsisr_hip_trace.so, read by
+// tools/trace_conv.py).  Thread 0 of each workgroup stamps the 100 MHz wall clock at phase boundaries.
+#ifdef SISR_CONV_TRACE
+#define SISR_TRACE_WG 4096
+#define SISR_TRACE_SLOTS 16
+__device__ unsigned long long sisr_trace_buf[SISR_TRACE_WG * SISR_TRACE_SLOTS];
+#define TR(k)                                                                                              \
+    do {                                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < SISR_TRACE_WG && blockIdx.y == 0)                             \
+            sisr_trace_buf[blockIdx.x * SISR_TRACE_SLOTS + (k)] = wall_clock64();                          \
+    } while (0)
+extern "C" int sisr_trace_read(void* dst, int n_u64) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sisr_trace_buf), (size_t)n_u64 * 8, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define TR(k)
+#endif
+
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -64,6 +82,33 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
     __bf16* lds_w = lds_in + ((npix * BF_PS + 16 + 7) & ~7);
     float* red = reinterpret_cast<float*>(lds_w);            // epilogue scratch (>= 5*BN floats)
 
+    TR(0);
+#ifdef SISR_CONV_TRACE
+    if (tid == 0 && blockIdx.x < SISR_TRACE_WG && blockIdx.y == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        sisr_trace_buf[blockIdx.x * SISR_TRACE_SLOTS + 15] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
+    // packed weights [chunk][CoutPad][WSG] bf16: a workgroup's slice of one chunk is contiguous, 16-byte vector
+    // v of it goes to LDS row v / wvec_row.  WVEC vectors per thread cover BN * WSG <= 64 * 288 elements.
+    constexpr int WVEC = (BN * 9 * BF_CK / 8 + SISR_BLOCK - 1) / SISR_BLOCK;
+    const int wvec_row = WSG >> 3;                       // 16-byte vectors per packed weight row
+    const int wvecs = BN * wvec_row;
+    const __amdgpu_buffer_rsrc_t wrs = bf_rsrc(d.wpk, (unsigned)p.wpk_elems * 2u);
+    // no per-lane predicate on the loads: vectors past the slice are in-bounds of the buffer (or read as zeros
+    // past its end) and are simply not written to LDS
+    const unsigned wvoff = (unsigned)tid * 16u;
+    bf16x8 wv[WVEC];
+    {
+        const unsigned cb = (unsigned)((blockIdx.y * BN) * WSG) * 2u;
+#pragma unroll
+        for (int u = 0; u < WVEC; ++u)
+            if (u * SISR_BLOCK < wvecs)
+                wv[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + u * (SISR_BLOCK * 16), cb, 0));
+    }
     int t = blockIdx.x;
     const int txi = t % p.tiles_x;
     t /= p.tiles_x;
@@ -91,6 +136,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
         row_off[m] = off;
     }
 
+    TR(13);
     const __bf16* ap[MSUB];
     const __bf16* bp[NSUB];
 #pragma unroll
@@ -115,45 +161,50 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ms][ns][i] = 0.f;
 
+    TR(14);
     OperandView ov;
     ov.x1 = d.x1; ov.x2 = d.x2; ov.pa = d.pa; ov.pb = d.pb; ov.pd = d.pd; ov.ps = d.ps; ov.pt = d.pt;
     ov.N = d.N; ov.H = d.H; ov.W = d.W; ov.C = d.Cin;
     ov.mode = d.x_mode; ov.pro = d.pro_mode;
     ov.slope = d.pro_slope_p ? d.pro_slope_p[0] : d.pro_slope;
     const int iy_org = oy0 * S - d.pad_y, ix_org = ox0 * S - d.pad_x;
-    const int wvec_row = WSG >> 3;                       // 16-byte vectors per packed weight row
-    const int wvecs = BN * wvec_row;
-    const __bf16* wsrc0 = reinterpret_cast<const __bf16*>(d.wpk);
+    const int wstep_j = SISR_BLOCK / wvec_row, wstep_k = SISR_BLOCK - wstep_j * wvec_row;
+    const int wstep_off = wstep_j * WS + wstep_k * 8;
+    const int wk0 = tid % wvec_row, woff0 = (tid / wvec_row) * WS + wk0 * 8;
 
     for (int chunk = 0; chunk < p.n_chunk; ++chunk) {
         __syncthreads();   // all fragment reads of the previous chunk are done
+        TR(1 + 4 * (chunk & 1));
         stage_operand_tile_bf16(ov, lds_in, BF_PS, BF_CK, chunk * BF_CK, p.TN, IH, IW, n0, iy_org, ix_org, 1 << 30);
-        {   // packed weights of this chunk: [BN][WSG] contiguous bf16 -> LDS [BN][WS]; the 16-byte loads of
-            // a thread are issued in batches before the first LDS write (no load->write->load latency chain)
-            const bf16x8* src = reinterpret_cast<const bf16x8*>(wsrc0 + ((int64_t)chunk * p.CoutPad + cout_base) * WSG);
-            constexpr int WB = 5;
-            for (int v0 = tid; v0 < wvecs; v0 += WB * SISR_BLOCK) {
-                bf16x8 wv[WB];
+        TR(2 + 4 * (chunk & 1));
+        {   // this chunk's packed weights are already in registers (loaded during the previous MFMA phase / the
+            // kernel prologue): write them to LDS, then put the next chunk's loads in flight
+            int wk = wk0, woff = woff0;
 #pragma unroll
-                for (int u = 0; u < WB; ++u)
-                    if (v0 + u * SISR_BLOCK < wvecs) wv[u] = src[v0 + u * SISR_BLOCK];
+            for (int u = 0; u < WVEC; ++u) {
+                if (tid + u * SISR_BLOCK < wvecs) *reinterpret_cast<bf16x8*>(lds_w + woff) = wv[u];
+                wk += wstep_k; woff += wstep_off;
+                if (wk >= wvec_row) { wk -= wvec_row; woff += 8; }
+            }
+            if (chunk + 1 < p.n_chunk) {
+                const unsigned cb = (unsigned)(((chunk + 1) * p.CoutPad + cout_base) * WSG) * 2u;
 #pragma unroll
-                for (int u = 0; u < WB; ++u) {
-                    const int v = v0 + u * SISR_BLOCK;
-                    if (v < wvecs) {
-                        const int j = v / wvec_row, k8 = v - j * wvec_row;
-                        *reinterpret_cast<bf16x8*>(lds_w + j * WS + k8 * 8) = wv[u];
-                    }
-                }
+                for (int u = 0; u < WVEC; ++u)
+                    if (u * SISR_BLOCK < wvecs)
+                        wv[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + u * (SISR_BLOCK * 16), cb, 0));
             }
         }
+        TR(3 + 4 * (chunk & 1));
         __syncthreads();
+        TR(4 + 4 * (chunk & 1));
         int tap = 0;
         for (int r = 0; r < d.KH; ++r)
             for (int s = 0; s < d.KW; ++s, ++tap)
                 conv_bf16_tap<MSUB, NSUB>(ap, bp, (r * IW + s) * BF_PS, tap * BF_CK, acc);
     }
+    TR(9);
     __syncthreads();   // LDS (weights region) is reused as reduction scratch below
+    TR(10);
 
     // ---- epilogue (identical to conv_fwd.hip: the 32x32 accumulator layout is dtype independent) ----
     int col_off[NSUB];
@@ -234,6 +285,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
         if (tid == 0 && blockIdx.y == 0) d.cnt_part[blockIdx.x] = cnt;
     }
 
+    TR(11);
     // residual / tanh flags are wave-uniform: hoisted out of the per-element loops
     int ro[MSUB][16];
 #pragma unroll
@@ -268,6 +320,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
                 for (int ns = 0; ns < NSUB; ++ns)
                     if (col_ok[ns]) d.y[(int64_t)ro[ms][i] + col_off[ns]] = acc[ms][ns][i];
             }
+    TR(12);
 }
 
 // ---- host ------------------------------------------------------------------------------------------
@@ -295,7 +348,7 @@ extern "C" int sisr_conv2d_plan_bf16(SisrConvDesc* d) {
     SisrConvPlan& p = d->plan;
     std::memset(&p, 0, sizeof(p));
     const int64_t ypix = std::max((int64_t)d->N * d->y_H * d->y_W, (int64_t)d->N * d->Ho * d->Wo);
-    if (ypix * d->Cout >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 31)) return SISR_E_TOOBIG;
+    if (ypix * d->Cout >= (1ll << 30) || (int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 30)) return SISR_E_TOOBIG;
     p.nsub = d->Cout <= 32 ? 1 : 2;
     const int BN = p.nsub * 32;
     p.CoutPad = round_up(d->Cout, BN);

@@ -8,12 +8,22 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define BF_CK 32
 #define BF_PS 40
 
-// float4 staging with the prologue fixed at compile time, bf16 LDS image (see stage_tile_vec)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// float4 staging with the prologue fixed at compile time, bf16 LDS image.
+// Addressing is the cheap part by construction: a thread's items walk the tile in steps of `ppi` pixels, so
+// its (row, column) and the two offset terms advance by adds; loads are raw buffer loads with a 32-bit byte
+// offset (tensor < 4 GB, checked by the planners) and pixels outside the image get an out-of-range offset,
+// which the hardware answers with zeros -- no divergent branch, no 64-bit address math, no multiplies.
 template <int PRO, int SBQ>
 __device__ __forceinline__ void stage_tile_bf16(const OperandView& o, __bf16* lds, int PS, int CK, int c0, int TN,
                                                 int IH, int IW, int n0, int iy_org, int ix_org, int valid_w) {
     constexpr bool need2 = PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD || PRO == SISR_PRO_ACT_BWD ||
                            PRO == SISR_PRO_TANH_BWD;
+    // prologues with f(0) != 0 need the halo forced to zero after the transform
+    constexpr bool mask_after = PRO == SISR_PRO_AFFINE_ACT || PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD;
     const int tid = threadIdx.x;
     const int G = CK >> 2;
     int lg = 0;
@@ -40,48 +50,59 @@ __device__ __forceinline__ void stage_tile_bf16(const OperandView& o, __bf16* ld
         const int ij = c / Cq;
         coff = c - ij * Cq; ysh = ij >> 1; xsh = ij & 1; Cp = Cq; Wp = 2 * o.W; Hp = 2 * o.H; mul = 2;
     }
-    const int xstep = mul * Cp;
-    // flat item loop, SB items per thread per batch: all global loads of a batch are issued before the first
-    // of them is consumed, so a tile costs ~one memory latency instead of one per item.  (row, column) of a
-    // thread's next pixel advance incrementally -- no per-item division.
+    const int col_step = mul * Cp * 4, row_step = mul * Wp * Cp * 4, img_step = Hp * Wp * Cp * 4;   // bytes
+    const unsigned nbytes = (unsigned)o.N * (unsigned)img_step;
+    const __amdgpu_buffer_rsrc_t r1 = bf_rsrc(o.x1, nbytes);
+    const __amdgpu_buffer_rsrc_t r2 = bf_rsrc(need2 ? o.x2 : o.x1, nbytes);
+    // byte offset of the tile origin for this thread's channel group (may be "negative": only used in range)
+    const int base = (((n0 * Hp + iy_org * mul + ysh) * Wp + ix_org * mul + xsh) * Cp + coff) * 4;
+
     constexpr int SB = need2 ? SBQ / 2 : SBQ;      // loads in flight per thread and operand
-    const int ppi = SISR_BLOCK >> lg;                    // pixels advanced per item step
+    const int ppi = SISR_BLOCK >> lg;              // pixels advanced per item step
     const int step_rows = ppi / IW, step_cols = ppi - step_rows * IW;
-    const int rows = TN * IH, npix = rows * IW;
+    const int npix = TN * IH * IW;
+    const int d_roff = step_rows * row_step, d_xoff = step_cols * col_step, wrap_xoff = IW * col_step;
     int pix = tid >> lg;
     int row = pix / IW, ixl = pix - row * IW;
+    int roff = row * row_step, xoff = ixl * col_step;
+    __bf16* dst = lds + pix * PS + g * 4;
+    const int dst_step = ppi * PS;
     for (; pix < npix; ) {
         f32x4 a[SB], b[need2 ? SB : 1];
-        int lds_off[SB];
         bool live[SB], ok[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
             live[u] = pix < npix;
-            int tn = 0, iyl = row;
-            if (TN > 1) { tn = row / IH; iyl = row - tn * IH; }
-            const int n = n0 + tn, iy = iy_org + iyl, ix = ix_org + ixl;
-            ok[u] = live[u] && c_ok && n < o.N && iy >= 0 && iy < o.H && ix >= 0 && ix < o.W && ixl < valid_w;
-            lds_off[u] = pix * PS + g * 4;
-            a[u] = zero;
-            if (need2) b[u] = zero;
-            if (ok[u]) {
-                const int off = ((n * Hp + iy * mul + ysh) * Wp + xsh) * Cp + coff + ix * xstep;
-                a[u] = *reinterpret_cast<const f32x4*>(o.x1 + off);
-                if (need2) b[u] = *reinterpret_cast<const f32x4*>(o.x2 + off);
+            int iyl = row, ro = roff;
+            bool n_ok = true;
+            if (TN > 1) {                           // whole small images per tile: rows run over (image, row)
+                const int tn = row / IH;
+                iyl = row - tn * IH;
+                ro = tn * img_step + iyl * row_step;
+                n_ok = n0 + tn < o.N;
             }
-            pix += ppi; row += step_rows; ixl += step_cols;
-            if (ixl >= IW) { ixl -= IW; ++row; }
+            const int iy = iy_org + iyl, ix = ix_org + ixl;
+            ok[u] = live[u] && c_ok && n_ok && (unsigned)iy < (unsigned)o.H && (unsigned)ix < (unsigned)o.W &&
+                    ixl < valid_w;
+            const unsigned voff = ok[u] ? (unsigned)(base + ro + xoff) : 0xFFFFFFF0u;
+            a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0));
+            if (need2) b[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0));
+            pix += ppi; row += step_rows; ixl += step_cols; roff += d_roff; xoff += d_xoff;
+            if (ixl >= IW) { ixl -= IW; ++row; roff += row_step; xoff -= wrap_xoff; }
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            if (live[u]) {
-                f32x4 v = zero;
-                if (ok[u]) v = apply4<PRO>(a[u], need2 ? b[u] : zero, ka, kb, kd, ks, kt, o.slope);
-                bf16x4 h;
-                h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-                *reinterpret_cast<bf16x4*>(lds + lds_off[u]) = h;
+            const f32x4 v = apply4<PRO>(a[u], need2 ? b[u] : zero, ka, kb, kd, ks, kt, o.slope);
+            bf16x4 h;
+            h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+            if (mask_after) {
+                uint2 hb = __builtin_bit_cast(uint2, h);
+                hb.x = ok[u] ? hb.x : 0u; hb.y = ok[u] ? hb.y : 0u;
+                h = __builtin_bit_cast(bf16x4, hb);
             }
+            if (live[u]) *reinterpret_cast<bf16x4*>(dst + u * dst_step) = h;
         }
+        dst += SB * dst_step;
     }
 }
 

@@ -7,8 +7,9 @@
 // is fetched with the gfx950 transposing LDS read ds_read_b64_tr_b16: per 16-lane group it reads a
 // 4-pixel x 16-channel block and hands lane i channel i of the 4 pixels (cdna_hip_programming.md T10);
 // two such reads make one 8-deep fragment.  One K step = 16 consecutive pixels of a tile row.
-// Workgroup = (32-channel chunk q, cout tile of NJ*32); wave = (jsub, pixel part); all KH*KW tap
-// accumulators stay resident; partial slabs are reduced by sisr_slab_reduce_f32 (deterministic).
+// Workgroup = (32-channel chunk q, cout tile of NJ*32); wave = (jsub, tap part): a wave keeps the
+// accumulators of its taps resident over all tiles of the workgroup; partial slabs (one per pixel block)
+// are reduced by sisr_slab_reduce_f32 (deterministic).
 // Requirements: Cin % 32 == 0, KH*KW <= 9, Cout % 4 == 0.
 #include "sisr_dev.h"
 
@@ -30,7 +31,35 @@ __device__ __forceinline__ bf16x8 frag8(const __bf16* p, int second_off) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int NTAP>
+// phase timeline, developer build only (see conv_bf16.hip / tools/trace_conv.py)
+#ifdef SISR_CONV_TRACE
+#define SISR_WTRACE_WG 2048
+#define SISR_WTRACE_SLOTS 32
+__device__ unsigned long long sisr_wtrace_buf[SISR_WTRACE_WG * SISR_WTRACE_SLOTS];
+#define WTR(k)                                                                                             \
+    do {                                                                                                   \
+        const int wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                               \
+        if (threadIdx.x == 0 && wg_ < SISR_WTRACE_WG && (k) < SISR_WTRACE_SLOTS)                           \
+            sisr_wtrace_buf[wg_ * SISR_WTRACE_SLOTS + (k)] = wall_clock64();                               \
+    } while (0)
+extern "C" int sisr_wtrace_read(void* dst, int n_u64) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sisr_wtrace_buf), (size_t)n_u64 * 8, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define WTR(k)
+#endif
+
+// LDS pixel strides (bf16 elements) chosen for the transposing reads: the 32 lanes of one LDS pass address
+// 4 pixels x 64 bytes, so a pixel stride of 16 or 48 banks (mod 64) puts them on 64 distinct banks.
+#define WG_PSX 32
+__host__ __device__ static inline int wg_dy_stride(int DCH) { return DCH == 32 ? 32 : DCH + 32; }
+
+// Wave roles: jsub = wave % NJ picks 32 output channels, tpart = wave / NJ picks TPW filter taps; every wave
+// walks ALL pixels of the tile, so no cross-wave reduction is needed and a wave keeps only TPW accumulators
+// (9 taps, NJ = 2: 5 + 4).  A wave whose tap range runs past the filter repeats the last tap and drops it.
+// K steps (16 consecutive pixels of a tile row) are software-pipelined through two fragment sets: the
+// transposing LDS reads of step k+1 are issued before the MFMAs of step k.
+template <int TPW>
 __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const SisrWgradDesc d) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -38,14 +67,15 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
     const int TWp = (d.TW + 15) & ~15;
     const int IH = (d.TH - 1) * S + d.KH, IW = (TWp - 1) * S + d.KW;
     const int npix_in = d.TN * IH * IW;
-    const int DCH = d.NJ * 32, DS = DCH + 8;
-    const int NP = 4 / d.NJ;
-    const int jsub = wave % d.NJ, ppart = wave / d.NJ;
+    const int DCH = d.NJ * 32, DS = wg_dy_stride(DCH);
+    const int ntap = d.KH * d.KW;
+    const int jsub = wave % d.NJ, tpart = wave / d.NJ;
+    const int tap0 = tpart * TPW;
     const int q = blockIdx.y % d.n_chunk, cot = blockIdx.y / d.n_chunk;
     const int co_base = cot * DCH;
 
     __bf16* lds_in = reinterpret_cast<__bf16*>(smem);
-    __bf16* lds_dy = lds_in + ((npix_in * BF_PS + 16 + 7) & ~7);
+    __bf16* lds_dy = lds_in + ((npix_in * WG_PSX + 16 + 7) & ~7);
 
     OperandView ox, og;
     ox.x1 = d.x1; ox.x2 = d.x2; ox.pa = d.pa; ox.pb = d.pb; ox.pd = d.pd; ox.ps = d.ps; ox.pt = d.pt;
@@ -61,30 +91,45 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
     const int pix_l = 8 * (grp >> 1) + tq;                 // pixel of this lane's address inside the K step
     const int ch_l = 16 * (grp & 1) + 4 * tp;              // first channel of this lane's address
 
-    int aoff[NTAP];
+    int aoff[TPW];
 #pragma unroll
-    for (int a = 0; a < NTAP; ++a) {
-        const int r = a / d.KW, s = a - r * d.KW;
-        aoff[a] = (r * IW + s) * BF_PS;
+    for (int a = 0; a < TPW; ++a) {
+        const int tap = min(tap0 + a, ntap - 1);
+        const int r = tap / d.KW, s = tap - r * d.KW;
+        aoff[a] = (r * IW + s) * WG_PSX;
     }
-    f32x16 acc[NTAP];
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int a = 0; a < NTAP; ++a)
+    for (int a = 0; a < TPW; ++a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
     float bias_acc = 0.f;
+    WTR(0);
+    int titer = 0;
 
-    for (int t = blockIdx.x; t < d.n_tiles; t += gridDim.x) {
+    const int nkx = TWp >> 4, nrows = d.TN * d.TH, nks = nrows * nkx;
+    const int dy_step = 16 * DS, in_step = 16 * S * WG_PSX;
+    const int in_row = (S * IW - (nkx - 1) * 16 * S) * WG_PSX;           // last K step of a row -> next row
+    const int in_img = ((IH - (d.TH - 1) * S) * IW - (nkx - 1) * 16 * S) * WG_PSX;   // ... -> next image
+    const __bf16* dy0 = lds_dy + pix_l * DS + jsub * 32 + ch_l;
+    const __bf16* in0 = lds_in + pix_l * S * WG_PSX + ch_l;
+    const int a2 = 4 * S * WG_PSX, b2 = 4 * DS;
+
+    for (int t = blockIdx.x; t < d.n_tiles; t += gridDim.x, ++titer) {
         int tt_ = t;
         const int txi = tt_ % d.tiles_x;
         tt_ /= d.tiles_x;
         const int tyi = tt_ % d.tiles_y, ng = tt_ / d.tiles_y;
         const int n0 = ng * d.TN, oy0 = tyi * d.TH, ox0 = txi * d.TW;
         __syncthreads();   // previous tile fully consumed
-        stage_operand_tile_bf16<4>(ox, lds_in, BF_PS, BF_CK, q * BF_CK, d.TN, IH, IW, n0, oy0 * S - d.pad_y,
+        WTR(1 + 5 * titer);
+        stage_operand_tile_bf16<8>(ox, lds_in, WG_PSX, BF_CK, q * BF_CK, d.TN, IH, IW, n0, oy0 * S - d.pad_y,
                                 ox0 * S - d.pad_x, 1 << 30);
-        stage_operand_tile_bf16<4>(og, lds_dy, DS, DCH, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, d.TW);
+        WTR(2 + 5 * titer);
+        stage_operand_tile_bf16<8>(og, lds_dy, DS, DCH, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, d.TW);
+        WTR(3 + 5 * titer);
         __syncthreads();
+        WTR(4 + 5 * titer);
         if (d.bias_slab != nullptr && q == 0) {
             // bias-gradient partial: every thread sums a strided share of the tile's pixels for one channel
             // (all 256 threads, independent loads) -- combined across the pixel shares after the tile loop
@@ -95,73 +140,58 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
             for (int px = share; px < npx; px += nshare) s += (float)lds_dy[px * DS + co];
             bias_acc += s;
         }
-        const int nrows = d.TN * d.TH;
-        for (int row = ppart; row < nrows; row += NP) {
-            const int tn = row / d.TH, ty = row - tn * d.TH;
-            const __bf16* dyp = lds_dy + (row * TWp + pix_l) * DS + jsub * 32 + ch_l;
-            const __bf16* inp = lds_in + ((tn * IH + ty * S) * IW + pix_l * S) * BF_PS + ch_l;
-            for (int tx0 = 0; tx0 < TWp; tx0 += 16) {
-                const bf16x8 bfrag = frag8(dyp + tx0 * DS, 4 * DS);
-                const __bf16* ip = inp + tx0 * S * BF_PS;
-                // taps in two groups to bound the live fragment registers (9 taps: 5 + 4)
-                constexpr int G0 = (NTAP + 1) / 2, G1 = NTAP - G0;
-                {
-                    bf16x8 af[G0];
+        // ---- pipelined K loop: position (kx, ty) of the NEXT step to fetch; fetching stops at the last step
+        const __bf16* dyp = dy0;
+        const __bf16* inp = in0;
+        int kfetch = 0, kx = 0, ty = 0;
+        bf16x8 bA, bB, aA[TPW], aB[TPW];
+        auto fetch = [&](bf16x8& bf, bf16x8 (&af)[TPW]) {
+            bf = frag8(dyp, b2);
 #pragma unroll
-                    for (int a = 0; a < G0; ++a) af[a] = frag8(ip + aoff[a], 4 * S * BF_PS);
-#pragma unroll
-                    for (int a = 0; a < G0; ++a)
-                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfrag, acc[a], 0, 0, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (G0 + 1), 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, G0, 0);
-                }
-                if (G1 > 0) {
-                    bf16x8 af[G1 > 0 ? G1 : 1];
-#pragma unroll
-                    for (int a = 0; a < G1; ++a) af[a] = frag8(ip + aoff[G0 + a], 4 * S * BF_PS);
-#pragma unroll
-                    for (int a = 0; a < G1; ++a)
-                        acc[G0 + a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfrag, acc[G0 + a], 0, 0, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * G1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, G1, 0);
-                }
+            for (int a = 0; a < TPW; ++a) af[a] = frag8(inp + aoff[a], a2);
+            if (kfetch + 1 < nks) {                       // uniform: advance to the next K step
+                ++kfetch;
+                dyp += dy_step;
+                int din = in_step;
+                if (++kx == nkx) { kx = 0; din = in_row; if (++ty == d.TH) { ty = 0; din = in_img; } }
+                inp += din;
             }
+        };
+        auto mma = [&](const bf16x8& bf, const bf16x8 (&af)[TPW]) {
+#pragma unroll
+            for (int a = 0; a < TPW; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf, acc[a], 0, 0, 0);
+        };
+        fetch(bA, aA);
+        for (int ks = 0; ks < nks; ks += 2) {
+            fetch(bB, aB);
+            mma(bA, aA);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TPW + 1), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TPW, 0);
+            fetch(bA, aA);
+            if (ks + 1 < nks) mma(bB, aB);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TPW + 1), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TPW, 0);
         }
+        WTR(5 + 5 * titer);
     }
+    WTR(28);
 
-    // ---- sum the pixel parts of each jsub through LDS ------------------------------------------------
-    __syncthreads();
-    for (int k = 1; k < NP; ++k) {
-        float* buf = smem + (size_t)jsub * (NTAP * 16 * 64);
-        if (ppart == k) {
-#pragma unroll
-            for (int a = 0; a < NTAP; ++a)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) buf[(a * 16 + i) * 64 + lane] = acc[a][i];
-        }
-        __syncthreads();
-        if (ppart == 0) {
-#pragma unroll
-            for (int a = 0; a < NTAP; ++a)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[a][i] += buf[(a * 16 + i) * 64 + lane];
-        }
-        __syncthreads();
-    }
-
-    if (ppart == 0) {
-        // slab layout [chunk][tap][ci (32)][CoutPad]
+    {   // slab layout [chunk][tap][ci (32)][CoutPad]: each wave owns its taps, no cross-wave reduction
         float* sl = d.slab + (int64_t)blockIdx.x * d.slab_stride;
 #pragma unroll
-        for (int a = 0; a < NTAP; ++a)
+        for (int a = 0; a < TPW; ++a) {
+            if (tap0 + a < ntap) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int ci = mfma_row(i, lane);
-                sl[((int64_t)(q * NTAP + a) * 32 + ci) * d.CoutPad + co_base + jsub * 32 + (lane & 31)] = acc[a][i];
+                for (int i = 0; i < 16; ++i) {
+                    const int ci = mfma_row(i, lane);
+                    sl[((int64_t)(q * ntap + tap0 + a) * 32 + ci) * d.CoutPad + co_base + jsub * 32 + (lane & 31)] = acc[a][i];
+                }
             }
+        }
     }
+    WTR(29);
     if (d.bias_slab != nullptr && q == 0) {
-        __syncthreads();                                   // LDS is free: all tiles and the part reduction are done
+        __syncthreads();                                   // LDS is free: all tiles are done
         float* bsh = smem;
         bsh[tid] = bias_acc;
         __syncthreads();
@@ -171,6 +201,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
             d.bias_slab[(int64_t)blockIdx.x * d.slab_stride + co_base + tid] = s;
         }
     }
+    WTR(30);
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -180,18 +211,18 @@ extern "C" int sisr_wgrad_plan_bf16(SisrWgradDesc* d, int32_t max_pixel_blocks) 
     if (d->stride != 1 && d->stride != 2) return SISR_E_BADARG;
     if ((d->Cin % BF_CK) || d->KH * d->KW > 9 || (d->Cout & 3)) return SISR_E_UNSUPPORTED;
     if (d->x_mode == SISR_X_NCHW || d->g_mode == SISR_X_NCHW) return SISR_E_UNSUPPORTED;
-    if ((int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 31) || (int64_t)d->N * d->Ho * d->Wo * d->Cout >= (1ll << 31))
+    if ((int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 30) || (int64_t)d->N * d->Ho * d->Wo * d->Cout >= (1ll << 30))
         return SISR_E_TOOBIG;
     d->CK = BF_CK; d->PS = BF_PS;
     d->KROWP = d->KH * d->KW * 32;        // rows per chunk in the slab: [tap][ci]
     d->n_chunk = d->Cin / BF_CK;
     d->NT = 1; d->TSTEP = 32; d->TVALID = 32;
     const int c32 = round_up(d->Cout, 32) / 32;
-    d->NJ = c32 >= 4 ? 4 : (c32 >= 2 ? 2 : 1);
+    d->NJ = c32 >= 2 ? 2 : 1;             // 64-wide cout tiles: 5 + 4 taps per wave pair (9 resident taps would spill)
     d->NP = 4 / d->NJ;
     d->CoutPad = round_up(d->Cout, d->NJ * 32);
-    const int S = d->stride, DS = d->NJ * 32 + 8;
-    const int red_bytes = d->NP > 1 ? d->NJ * (d->KH * d->KW) * 16 * 64 * 4 : 0;
+    const int S = d->stride, DS = wg_dy_stride(d->NJ * 32);
+    const int red_bytes = SISR_BLOCK * 4;               // bias partial combine
     double best = -1.0;
     for (int BMW = 256; BMW >= 64 && best < 0; BMW >>= 1) {
         for (int TW = 1; TW <= std::min(d->Wo, BMW); ++TW) {
@@ -202,7 +233,7 @@ extern "C" int sisr_wgrad_plan_bf16(SisrWgradDesc* d, int32_t max_pixel_blocks) 
             int TN = 1;
             if (TH == d->Ho && TW == d->Wo) TN = std::max(1, std::min(d->N, BMW / (TH * TWp)));
             const int IH = (TH - 1) * S + d->KH, IW = (TWp - 1) * S + d->KW;
-            const int in_elems = (TN * IH * IW * BF_PS + 16 + 7) & ~7;
+            const int in_elems = (TN * IH * IW * WG_PSX + 16 + 7) & ~7;
             const int lds = std::max((in_elems + TN * TH * TWp * DS + 16) * 2, red_bytes);
             if (lds > 80 * 1024) continue;
             const int ty = (d->Ho + TH - 1) / TH, tx = (d->Wo + TW - 1) / TW, ngr = (d->N + TN - 1) / TN;
@@ -228,17 +259,17 @@ extern "C" int sisr_wgrad_plan_bf16(SisrWgradDesc* d, int32_t max_pixel_blocks) 
     return 0;
 }
 
-template <int NTAP>
+template <int TPW>
 static int launch_wgrad_bf16(const SisrWgradDesc* d, hipStream_t st) {
     static int lds_max = 64 * 1024;
     if (d->lds_bytes > lds_max) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_bf16_kernel<NTAP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_bf16_kernel<TPW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_bytes);
         if (e != hipSuccess) return (int)e;
         lds_max = d->lds_bytes;
     }
     const dim3 grid(d->grid_x, d->n_chunk * (d->CoutPad / (d->NJ * 32)));
-    hipLaunchKernelGGL(wgrad_mfma_bf16_kernel<NTAP>, grid, dim3(SISR_BLOCK), d->lds_bytes, st, *d);
+    hipLaunchKernelGGL(wgrad_mfma_bf16_kernel<TPW>, grid, dim3(SISR_BLOCK), d->lds_bytes, st, *d);
     SISR_CHECK_LAUNCH();
     return 0;
 }
@@ -250,11 +281,13 @@ extern "C" int sisr_conv2d_wgrad_bf16(const SisrWgradDesc* d, void* stream) {
     if (d->slab_stride < d->slab_elems || d->CK != BF_CK || d->PS != BF_PS) return SISR_E_BADARG;
     if (d->grid_x <= 0 || d->lds_bytes <= 0 || d->lds_bytes > 160 * 1024) return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    switch (d->KH * d->KW) {
+    const int np = 4 / d->NJ, ntap = d->KH * d->KW;
+    switch ((ntap + np - 1) / np) {                        // taps per wave
         case 1: return launch_wgrad_bf16<1>(d, st);
         case 2: return launch_wgrad_bf16<2>(d, st);
         case 3: return launch_wgrad_bf16<3>(d, st);
         case 4: return launch_wgrad_bf16<4>(d, st);
+        case 5: return launch_wgrad_bf16<5>(d, st);
         case 6: return launch_wgrad_bf16<6>(d, st);
         case 9: return launch_wgrad_bf16<9>(d, st);
     }

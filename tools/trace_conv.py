@@ -1,0 +1,43 @@
+"""Phase timeline of the generic bf16 conv kernel for the trunk layer (developer tool).
+Build `make -C single-image-super-resolution_amd/csrc trace`, then run with
+SISR_LIB=.../libsisr_hip_trace.so python tools/trace_conv.py.  Prints per-phase durations (us) averaged over
+workgroups, the workgroup lifetime, and the number of workgroups per CU."""
+import ctypes as C, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+import bench
+dev = torch.device('cuda', 0)
+bench.sub('engine').set_precision('bf16')
+print(bench.dominant_kernel_roofline(dev, 'bf16', iters=3))
+torch.cuda.synchronize()
+L = C.CDLL(os.environ['SISR_LIB'])
+n_wg, slots = 1152, 16
+buf = np.zeros(n_wg * slots, dtype=np.uint64)
+rc = L.sisr_trace_read(buf.ctypes.data_as(C.c_void_p), C.c_int(buf.size))
+assert rc == 0, rc
+t = buf.reshape(n_wg, slots).astype(np.int64)
+hw = t[:, 15]
+setup = t[:, 13:15] * 10e-3
+t = t[:, :13] * 10e-3          # 100 MHz ticks -> us
+t0 = t[:, 0].min()
+names = ['start', 'c0 sync', 'c0 input staged', 'c0 weights staged', 'c0 barrier', 'c1 sync(MFMA c0 done)',
+         'c1 input staged', 'c1 weights staged', 'c1 barrier', 'MFMA c1 done', 'barrier', 'stats done', 'stores done']
+print('kernel span %.2f us; workgroup lifetime avg %.2f us (min %.2f max %.2f)' % (
+    t[:, 12].max() - t0, (t[:, 12] - t[:, 0]).mean(), (t[:, 12] - t[:, 0]).min(), (t[:, 12] - t[:, 0]).max()))
+print('setup: row table +%.2f, fragment pointers +%.2f' % ((setup[:, 0] - t[:, 0]).mean(), (setup[:, 1] - setup[:, 0]).mean()))
+for k in range(1, 13):
+    dlt = t[:, k] - t[:, k - 1]
+    print('%-26s +%.2f us (p10 %.2f p90 %.2f)' % (names[k], dlt.mean(), np.percentile(dlt, 10), np.percentile(dlt, 90)))
+start = t[:, 0] - t0
+print('start times: p0 %.2f p25 %.2f p50 %.2f p75 %.2f p100 %.2f' % tuple(np.percentile(start, [0, 25, 50, 75, 100])))
+cu = ((hw >> 32) << 16) | (((hw >> 13) & 7) << 8) | ((hw >> 8) & 15)          # xcc | se | cu
+u, cnt = np.unique(cu, return_counts=True)
+print('CUs used %d; workgroups per CU min %d max %d' % (len(u), cnt.min(), cnt.max()))
+# concurrency: how many workgroups of the same CU overlap at the median start of each
+ov = []
+for c in u[:64]:
+    m = cu == c
+    s, e = t[m, 0], t[m, 12]
+    ov.append(np.mean([(np.sum((s <= x) & (e > x))) for x in s]))
+print('avg concurrent workgroups per CU (sampled at starts): %.2f' % np.mean(ov))
