@@ -38,6 +38,17 @@ extern "C" int sisr_trace_read(void* dst, int n_u64) {
 #define TR(k)
 #endif
 
+// merge two (count, mean, M2) partials (Chan, Golub, LeVeque); either side may be empty
+__device__ __forceinline__ void stat_merge(float& n, float& mu, float& m2, float nb, float mub, float m2b) {
+    const float nt = n + nb;
+    if (nt > 0.f) {
+        const float dl = mub - mu, f = nb / nt;
+        mu += dl * f;
+        m2 += m2b + dl * dl * n * f;
+    }
+    n = nt;
+}
+
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -80,7 +91,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
     int* row_off = reinterpret_cast<int*>(smem);
     __bf16* lds_in = reinterpret_cast<__bf16*>(smem + BM);
     __bf16* lds_w = lds_in + ((npix * BF_PS + 16 + 7) & ~7);
-    float* red = reinterpret_cast<float*>(lds_w);            // epilogue scratch (>= 5*BN floats)
+    float* red = reinterpret_cast<float*>(lds_w);            // epilogue scratch (12*BN floats)
 
     TR(0);
 #ifdef SISR_CONV_TRACE
@@ -230,78 +241,82 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
             for (int i = 0; i < 16; ++i) acc[ms][ns][i] += bv;
     }
 
-    if (d.stat_part != nullptr) {
-        float* meanb = red + 4 * BN;
-        const int vn = min(p.TN, d.N - n0), vh = min(p.TH, d.Ho - oy0), vw = min(p.TW, d.Wo - ox0);
-        const float cnt = (float)(vn * vh * vw);
-        float s[NSUB];
+    // this lane's accumulator rows: byte offset of the output pixel, or the out-of-range marker 2^31 (tensors
+    // are < 2 GB, so marker + any channel offset stays out of range and the hardware drops the access)
+    unsigned rb[MSUB][16];
+    bool rv[MSUB][16];
 #pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) s[ns] = 0.f;
+    for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = row_off[wave * (MSUB * 32) + ms * 32 + mfma_row(i, lane)];
+            rv[ms][i] = o >= 0;
+            rb[ms][i] = o >= 0 ? (unsigned)o * 4u : 0x80000000u;
+        }
+
+    if (d.stat_part != nullptr) {
+        // BatchNorm statistics of the tile, one pass: every lane reduces its rows to (count, mean, M2), the
+        // partials are merged pairwise (Chan et al.) -- lane halves by a shuffle, the 4 waves through LDS in a
+        // fixed order (deterministic) -- one barrier instead of a two-pass mean / deviation scheme
+        float n = 0.f;
 #pragma unroll
         for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = wave * (MSUB * 32) + ms * 32 + mfma_row(i, lane);
-                if (row_off[row] >= 0) {
-#pragma unroll
-                    for (int ns = 0; ns < NSUB; ++ns) s[ns] += acc[ms][ns][i];
-                }
-            }
+            for (int i = 0; i < 16; ++i) n += rv[ms][i] ? 1.f : 0.f;
+        const float inv = n > 0.f ? 1.f / n : 0.f;
+        const float n_o = __shfl_xor(n, 32);
 #pragma unroll
         for (int ns = 0; ns < NSUB; ++ns) {
-            s[ns] += __shfl_xor(s[ns], 32);
-            if (kk == 0) red[wave * BN + ns * 32 + l31] = s[ns];
-        }
-        __syncthreads();
-        if (tid < BN) meanb[tid] = (red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid]) / cnt;
-        __syncthreads();
+            float sm = 0.f;
 #pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) {
-            const float mu = meanb[ns * 32 + l31];
-            float q = 0.f;
+            for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sm += rv[ms][i] ? acc[ms][ns][i] : 0.f;
+            float mu = sm * inv, m2 = 0.f;
 #pragma unroll
             for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int row = wave * (MSUB * 32) + ms * 32 + mfma_row(i, lane);
-                    if (row_off[row] >= 0) {
-                        const float dv = acc[ms][ns][i] - mu;
-                        q += dv * dv;
-                    }
+                    const float dv = acc[ms][ns][i] - mu;
+                    m2 += rv[ms][i] ? dv * dv : 0.f;
                 }
-            s[ns] = q + __shfl_xor(q, 32);
+            float nn = n;
+            stat_merge(nn, mu, m2, n_o, __shfl_xor(mu, 32), __shfl_xor(m2, 32));
+            if (kk == 0) {
+                float* r = red + (wave * BN + ns * 32 + l31) * 3;
+                r[0] = nn; r[1] = mu; r[2] = m2;
+            }
         }
-        __syncthreads();
-#pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns)
-            if (kk == 0) red[wave * BN + ns * 32 + l31] = s[ns];
         __syncthreads();
         if (tid < BN && cout_base + tid < d.Cout) {
-            const float m2 = red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid];
+            float nn = red[tid * 3], mu = red[tid * 3 + 1], m2 = red[tid * 3 + 2];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float* r = red + (w * BN + tid) * 3;
+                stat_merge(nn, mu, m2, r[0], r[1], r[2]);
+            }
             float* sp = d.stat_part + (int64_t)blockIdx.x * 2 * d.Cout + cout_base + tid;
-            sp[0] = meanb[tid];
+            sp[0] = mu;
             sp[d.Cout] = m2;
+            if (tid == 0 && blockIdx.y == 0) d.cnt_part[blockIdx.x] = nn;
         }
-        if (tid == 0 && blockIdx.y == 0) d.cnt_part[blockIdx.x] = cnt;
     }
-
     TR(11);
-    // residual / tanh flags are wave-uniform: hoisted out of the per-element loops
-    int ro[MSUB][16];
-#pragma unroll
-    for (int ms = 0; ms < MSUB; ++ms)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) ro[ms][i] = row_off[wave * (MSUB * 32) + ms * 32 + mfma_row(i, lane)];
+
+    // output (and residual) through raw buffer accesses with 32-bit byte offsets
+    const unsigned ybytes = (unsigned)max(d.N * d.y_H * d.y_W, d.N * d.Ho * d.Wo) * (unsigned)d.Cout * 4u;
+    const __amdgpu_buffer_rsrc_t ry = bf_rsrc(d.y, ybytes);
     if (d.res != nullptr) {
+        const __amdgpu_buffer_rsrc_t rr = bf_rsrc(d.res, ybytes);
 #pragma unroll
-        for (int ms = 0; ms < MSUB; ++ms)
+        for (int ns = 0; ns < NSUB; ++ns)
+            if (col_ok[ns]) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (ro[ms][i] >= 0) {
+                for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
-                    for (int ns = 0; ns < NSUB; ++ns)
-                        if (col_ok[ns]) acc[ms][ns][i] += d.res[(int64_t)ro[ms][i] + col_off[ns]];
-                }
+                    for (int i = 0; i < 16; ++i)
+                        acc[ms][ns][i] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, rb[ms][i] + (unsigned)col_off[ns] * 4u, 0, 0));
+            }
     }
     if (d.epi_act == SISR_EPI_TANH) {
 #pragma unroll
@@ -312,14 +327,17 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
                 for (int i = 0; i < 16; ++i) acc[ms][ns][i] = tanhf(acc[ms][ns][i]);
     }
 #pragma unroll
-    for (int ms = 0; ms < MSUB; ++ms)
+    for (int ns = 0; ns < NSUB; ++ns)
+        if (col_ok[ns]) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (ro[ms][i] >= 0) {
+            for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
-                for (int ns = 0; ns < NSUB; ++ns)
-                    if (col_ok[ns]) d.y[(int64_t)ro[ms][i] + col_off[ns]] = acc[ms][ns][i];
-            }
+                for (int i = 0; i < 16; ++i) {
+                    // (a bit_cast applied directly to a vector element reads element 0 with this compiler)
+                    const float val = acc[ms][ns][i];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ry, rb[ms][i] + (unsigned)col_off[ns] * 4u, 0, 0);
+                }
+        }
     TR(12);
 }
 
@@ -329,7 +347,7 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static int conv_bf16_lds_bytes(int BM, int TN, int TH, int TW, int S, int KH, int KW, int BN) {
     const int IH = (TH - 1) * S + KH, IW = (TW - 1) * S + KW;
     const int in_elems = (TN * IH * IW * BF_PS + 16 + 7) & ~7;
-    const int w_bytes = std::max(BN * (KH * KW * BF_CK + 8) * 2, 5 * BN * 4);
+    const int w_bytes = std::max(BN * (KH * KW * BF_CK + 8) * 2, 12 * BN * 4);       // weights / statistics scratch
     return BM * 4 + in_elems * 2 + w_bytes + 16;
 }
 
@@ -348,7 +366,8 @@ extern "C" int sisr_conv2d_plan_bf16(SisrConvDesc* d) {
     SisrConvPlan& p = d->plan;
     std::memset(&p, 0, sizeof(p));
     const int64_t ypix = std::max((int64_t)d->N * d->y_H * d->y_W, (int64_t)d->N * d->Ho * d->Wo);
-    if (ypix * d->Cout >= (1ll << 30) || (int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 30)) return SISR_E_TOOBIG;
+    // 32-bit buffer addressing: input < 4 GB, output < 2 GB (its out-of-range marker is 2^31)
+    if (ypix * d->Cout >= (1ll << 29) || (int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 30)) return SISR_E_TOOBIG;
     p.nsub = d->Cout <= 32 ? 1 : 2;
     const int BN = p.nsub * 32;
     p.CoutPad = round_up(d->Cout, BN);

@@ -354,8 +354,8 @@ __global__ void __launch_bounds__(PC_THREADS, 1) conv_c64_bf16_persist_kernel(co
                 for (int i = 0; i < 16; ++i) {
                     const unsigned so = rbase + (unsigned)((i & 3) + 8 * (i >> 2)) * ps4;
                     if (full || mfma_row(i, lane) < vw) {
-                        if (col_ok0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc0[i]), ry, voff0, so, 0);
-                        if (col_ok1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc1[i]), ry, voff1, so, 0);
+                        if (col_ok0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)acc0[i]), ry, voff0, so, 0);
+                        if (col_ok1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)acc1[i]), ry, voff1, so, 0);
                     }
                 }
             }
