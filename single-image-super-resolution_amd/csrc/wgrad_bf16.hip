@@ -223,36 +223,41 @@ extern "C" int sisr_wgrad_plan_bf16(SisrWgradDesc* d, int32_t max_pixel_blocks) 
     d->CoutPad = round_up(d->Cout, d->NJ * 32);
     const int S = d->stride, DS = wg_dy_stride(d->NJ * 32);
     const int red_bytes = SISR_BLOCK * 4;               // bias partial combine
+    // tile choice: the workgroups of one pixel block walk ceil(n_tiles / grid_x) tiles in sequence, so the cost
+    // of a plan is that round count times the work of one tile (dy pixels incl. padding, the half-as-wide
+    // x halo tile, a fixed per-tile synchronisation charge) -- this also balances the tail round
+    const int per_pixel_block = d->n_chunk * (d->CoutPad / (d->NJ * 32));
+    const int gx_max = std::max(1, max_pixel_blocks / per_pixel_block);
     double best = -1.0;
-    for (int BMW = 256; BMW >= 64 && best < 0; BMW >>= 1) {
-        for (int TW = 1; TW <= std::min(d->Wo, BMW); ++TW) {
-            const int TWp = (TW + 15) & ~15;
-            if (TWp > BMW) continue;
-            const int TH = std::min(d->Ho, BMW / TWp);
-            if (TH < 1) continue;
-            int TN = 1;
-            if (TH == d->Ho && TW == d->Wo) TN = std::max(1, std::min(d->N, BMW / (TH * TWp)));
-            const int IH = (TH - 1) * S + d->KH, IW = (TWp - 1) * S + d->KW;
-            const int in_elems = (TN * IH * IW * WG_PSX + 16 + 7) & ~7;
-            const int lds = std::max((in_elems + TN * TH * TWp * DS + 16) * 2, red_bytes);
-            if (lds > 80 * 1024) continue;
-            const int ty = (d->Ho + TH - 1) / TH, tx = (d->Wo + TW - 1) / TW, ngr = (d->N + TN - 1) / TN;
-            const double eff = (double)d->N * d->Ho * d->Wo / ((double)ty * tx * ngr * TN * TH * TWp);
-            const double halo = (double)(TH * TW) * S * S / ((double)IH * IW);
-            const double fill = (double)(TN * TH * TWp) / BMW;
-            const double score = eff * (0.7 + 0.3 * halo) * (0.8 + 0.2 * fill);
-            if (score > best + 1e-9) {
-                best = score;
-                d->TH = TH; d->TW = TW; d->TN = TN; d->tiles_y = ty; d->tiles_x = tx; d->n_groups = ngr;
-                d->lds_bytes = lds;
+    for (int BMW = 256; BMW >= 64; BMW >>= 1) {
+        for (int TW16 = 16; TW16 <= BMW; TW16 += 16) {          // tile widths: multiples of the K step, or the image
+            const int TW = std::min(d->Wo, TW16), TWp = (TW + 15) & ~15;
+            if (TWp != TW16) break;
+            for (int TH = std::min(d->Ho, BMW / TWp); TH >= std::min(d->Ho, 4); --TH) {
+                int TN = 1;
+                if (TH == d->Ho && TW == d->Wo) TN = std::max(1, std::min(d->N, BMW / (TH * TWp)));
+                const int IH = (TH - 1) * S + d->KH, IW = (TWp - 1) * S + d->KW;
+                const int in_elems = (TN * IH * IW * WG_PSX + 16 + 7) & ~7;
+                const int lds = std::max((in_elems + TN * TH * TWp * DS + 16) * 2, red_bytes);
+                if (lds > 80 * 1024) continue;
+                const int ty = (d->Ho + TH - 1) / TH, tx = (d->Wo + TW - 1) / TW, ngr = (d->N + TN - 1) / TN;
+                const int64_t nt = (int64_t)ty * tx * ngr;
+                const int64_t gx = std::min<int64_t>(gx_max, nt);
+                const double rounds = (double)((nt + gx - 1) / gx);
+                const double work = (double)TN * TH * TWp + 0.5 * TN * IH * IW + 48.0;
+                const double score = 1.0 / (rounds * work);
+                if (score > best * (1.0 + 1e-9)) {
+                    best = score;
+                    d->TH = TH; d->TW = TW; d->TN = TN; d->tiles_y = ty; d->tiles_x = tx; d->n_groups = ngr;
+                    d->lds_bytes = lds;
+                }
+                if (TH * TWp <= BMW / 2) break;           // smaller heights belong to the next BMW
             }
         }
     }
     if (best < 0) return SISR_E_TOOBIG;
     d->n_tiles = d->tiles_y * d->tiles_x * d->n_groups;
-    const int per_pixel_block = d->n_chunk * (d->CoutPad / (d->NJ * 32));
-    const int gx = std::max(1, max_pixel_blocks / per_pixel_block);
-    d->grid_x = std::min(gx, d->n_tiles);
+    d->grid_x = std::min(gx_max, d->n_tiles);
     d->n_slabs = d->grid_x;
     d->slab_elems = d->n_chunk * d->KROWP * d->CoutPad;
     d->slab_stride = d->slab_elems;
