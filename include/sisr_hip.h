@@ -238,6 +238,11 @@ int sisr_nhwc_to_nchw(const float *x, const float *pa, const float *pd, const fl
  * (lrelu'(mask_pre)) : 1) is NOT applied here: plain layout change. */
 int sisr_nchw_to_nhwc(const float *x, int64_t src_stride, float *y, int32_t N, int32_t H, int32_t W,
                       int32_t C, void *stream);
+/* NCHW gradient (C <= Cpad channels) -> NHWC [N][H][W][Cpad] with zero padding channels; out != NULL fuses the
+ * tanh backward g = dy*(1 - out^2) of the generator's last layer (model_generator.py:54, nn.Tanh after the
+ * final conv).  Feeds the bf16 weight gradient of that 3-channel conv. */
+int sisr_nchw_grad_to_nhwc4(const float *dy, const float *out, float *g, int32_t N, int32_t C, int32_t H,
+                            int32_t W, int32_t Cpad, void *stream);
 
 /* ---- MaxPool2d(2,2) of the VGG19 stack (model_content_extractor.py:43; floors odd sizes), NHWC.
  * Pooling commutes with the (monotonic) ReLU in front of it, so the forward pools the RAW conv

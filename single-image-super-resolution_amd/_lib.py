@@ -101,6 +101,7 @@ _SIGS = {
     'sisr_add': [_f, _f, _f, _i64, _f],
     'sisr_nhwc_to_nchw': [_f, _f, _f, _f, _f32, _f, _i64, _i32, _i32, _i32, _i32, _f],
     'sisr_nchw_to_nhwc': [_f, _i64, _f, _i32, _i32, _i32, _i32, _f],
+    'sisr_nchw_grad_to_nhwc4': [_f, _f, _f, _i32, _i32, _i32, _i32, _i32, _f],
     'sisr_maxpool2_fwd': [_f, _f, _i32, _i32, _i32, _i32, _f],
     'sisr_maxpool2_relu_bwd': [_f, _f, _f, _i32, _i32, _i32, _i32, _f],
     'sisr_add_relu_masked': [_f, _f, _f, _f, _i64, _f],

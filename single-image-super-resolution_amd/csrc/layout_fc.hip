@@ -54,6 +54,30 @@ __global__ void __launch_bounds__(SISR_BLOCK) nchw_to_nhwc_kernel(const float* _
     }
 }
 
+// ---- NCHW gradient image (few channels) -> NHWC padded to a multiple of 4 channels, with the tanh-backward
+// transform fused: g[n][p][c] = dy * (1 - out^2) (or dy).  Feeds the bf16 weight-gradient kernel of the
+// generator's last convolution (Cout = 3), whose dy operand would otherwise be a scalar NCHW gather.
+__global__ void __launch_bounds__(SISR_BLOCK) nchw_grad_to_nhwc4_kernel(const float* __restrict__ dy,
+                                                                        const float* __restrict__ out, float* __restrict__ g,
+                                                                        int64_t HW, int C, int Cp, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * SISR_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * SISR_BLOCK) {
+        const int64_t n = i / HW, p = i - n * HW;
+        for (int c4 = 0; c4 < Cp; c4 += 4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (c4 + j < C) {
+                    const int64_t o = (n * C + c4 + j) * HW + p;
+                    float t = dy[o];
+                    if (out != nullptr) { const float y = out[o]; t *= 1.f - y * y; }
+                    v[j] = t;
+                }
+            }
+            *reinterpret_cast<f32x4*>(g + i * Cp + c4) = v;
+        }
+    }
+}
+
 // ---- FC forward: workgroup = FC_R weight rows, threads stride over K in float4 ----------------------
 #define FC_R 4
 #define FC_B 16
@@ -319,6 +343,16 @@ extern "C" int sisr_nchw_to_nhwc(const float* x, int64_t src_stride, float* y, i
     const int HW = H * W;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 31) / 32, (C + 31) / 32, N), dim3(SISR_BLOCK), 0, S_(stream),
                        x, src_stride, y, HW, C);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_nchw_grad_to_nhwc4(const float* dy, const float* out, float* g, int32_t N, int32_t C, int32_t H,
+                                       int32_t W, int32_t Cpad, void* stream) {
+    if (!dy || !g || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C || (Cpad & 3)) return SISR_E_BADARG;
+    const int64_t HW = (int64_t)H * W, total = (int64_t)N * HW;
+    const int grid = (int)std::min<int64_t>((total + SISR_BLOCK - 1) / SISR_BLOCK, 4096);
+    hipLaunchKernelGGL(nchw_grad_to_nhwc4_kernel, dim3(grid), dim3(SISR_BLOCK), 0, S_(stream), dy, out, g, HW, C, Cpad, total);
     SISR_CHECK_LAUNCH();
     return 0;
 }

@@ -147,9 +147,14 @@ class ConvGeom:
         g.N, g.H, g.W, g.Cin, g.Ho, g.Wo, g.Cout = n, h, w, self.cin, ho, wo, self.cout
         g.KH = g.KW = self.k
         g.stride, g.pad_y, g.pad_x = self.stride, self.pad, self.pad
-        g_bf = (want_bf16 and self.cin % 32 == 0 and self.cout % 4 == 0 and
-                lib.sisr_wgrad_plan_bf16(C.byref(g), max_pixel_blocks) == 0)
+        g_bf = False
+        if want_bf16 and self.cin % 32 == 0:
+            # few-channel outputs (the generator's 3-channel last conv): the bf16 kernel runs on the gradient
+            # image padded to 4 channels (conv_wgrad materialises it), 16x the exact-fp32 matrix rate
+            g.Cout = (self.cout + 3) // 4 * 4 if self.cout < 32 else self.cout
+            g_bf = g.Cout % 4 == 0 and lib.sisr_wgrad_plan_bf16(C.byref(g), max_pixel_blocks) == 0
         if not g_bf:
+            g.Cout = self.cout
             L.check(lib.sisr_wgrad_plan(C.byref(g), max_pixel_blocks), 'sisr_wgrad_plan')
         g.slab_stride = g.slab_elems + g.CoutPad
         self._plans[key] = (f, d, g, (bool(f_bf), bool(d_bf), bool(g_bf)))
@@ -365,9 +370,18 @@ def conv_wgrad(prep, x_op, dy_op):
     """Weight + bias gradient in packed layout: returns the reduced [slab_elems + CoutPad] buffer."""
     lib = L.lib()
     g = _copy_struct(prep.plans[2])
-    assert tuple(x_op.dims) == (g.N, g.H, g.W, g.Cin) and tuple(dy_op.dims) == (g.N, g.Ho, g.Wo, g.Cout), \
+    cout = prep.ref.geom.cout
+    assert tuple(x_op.dims) == (g.N, g.H, g.W, g.Cin) and tuple(dy_op.dims) == (g.N, g.Ho, g.Wo, cout), \
         (x_op.dims, dy_op.dims)
     dev = x_op.x1.device
+    if g.Cout != cout:          # bf16 kernel on a channel-padded NHWC copy of the (NCHW, few-channel) gradient
+        if dy_op.mode != L.X_NCHW or dy_op.pro not in (L.PRO_NONE, L.PRO_TANH_BWD):
+            raise RuntimeError('padded weight gradient: NCHW gradient with no / tanh-backward prologue expected')
+        g4 = torch.empty((g.N, g.Ho, g.Wo, g.Cout), dtype=torch.float32, device=dev)
+        L.check(lib.sisr_nchw_grad_to_nhwc4(dy_op.x1.data_ptr(), _ptr(dy_op.x2) if dy_op.pro == L.PRO_TANH_BWD else None,
+                                            g4.data_ptr(), g.N, cout, g.Ho, g.Wo, g.Cout, _stream()),
+                'sisr_nchw_grad_to_nhwc4')
+        dy_op = Operand.plain(g4)
     stride = g.slab_stride
     slab = torch.empty((g.n_slabs, stride), dtype=torch.float32, device=dev)
     x_op.fill(g)

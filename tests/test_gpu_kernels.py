@@ -270,3 +270,30 @@ def test_conv_bf16_forward_dgrad_wgrad(E, L, case):
         assert maxrel(nchw(dx), xr.grad) < BF16_TOL, 'dgrad'
     finally:
         E.set_precision('fp32')
+
+
+def test_wgrad_bf16_few_channel_output_padded(E, L):
+    """the generator's last conv (64 -> 3 + tanh): its weight gradient runs on the bf16 kernel over a
+    4-channel NHWC copy of the NCHW gradient with the tanh backward fused into the copy"""
+    n, cin, cout, k, h, w = 2, 64, 3, 3, 20, 24
+    x = _rand((n, cin, h, w), 11)
+    wt = _rand((cout, cin, k, k), 12, 0.05)
+    b = _rand((cout,), 13, 0.1)
+    xr, wr, br = x.clone(), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = torch.tanh(F.conv2d(xr, wr, br, padding=1))
+    r = _rand(tuple(y_ref.shape), 14)
+    (y_ref * r).sum().backward()
+    E.set_precision('bf16')
+    try:
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(cin, cout, k, 1, 1))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        assert p.kinds[2] and p.plans[2].Cout == 4
+        dy = E.Operand(r.cuda(), (n, h, w, cout), pro=L.PRO_TANH_BWD, mode=L.X_NCHW, x2=y_ref.detach().cuda())
+        red = E.conv_wgrad(p, E.Operand.plain(nhwc(x).cuda()), dy)
+        wg = E.WeightGradBatch()
+        wg.add(p, red)
+        gw, gb = wg.run()[id(ref)]
+        assert maxrel(gw, wr.grad) < BF16_TOL, 'wgrad'
+        assert maxrel(gb, br.grad) < BF16_TOL, 'bias grad'
+    finally:
+        E.set_precision('fp32')
