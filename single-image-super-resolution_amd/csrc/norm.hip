@@ -189,7 +189,15 @@ __global__ void __launch_bounds__(SISR_BLOCK) prelu_slope_partial_kernel(const f
                                                                          int64_t n, float* work) {
     __shared__ float scratch[8];
     float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * SISR_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SISR_BLOCK) {
+    const int64_t n4 = n >> 2;                               // 16-byte loads; buffers come from the allocator (aligned)
+    for (int64_t i = (int64_t)blockIdx.x * SISR_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * SISR_BLOCK) {
+        const f32x4 p = reinterpret_cast<const f32x4*>(pre)[i], g = reinterpret_cast<const f32x4*>(dy)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (!(p[j] > 0.f)) s += g[j] * p[j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
         const float p = pre[i];
         if (!(p > 0.f)) s += dy[i] * p;
     }
@@ -207,8 +215,13 @@ __global__ void __launch_bounds__(SISR_BLOCK) sum_partials_kernel(const float* w
 
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
                            int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(y)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
         y[i] = a[i] + b[i];
+    }
 }
 
 // ---- C ABI ----------------------------------------------------------------------------------------
@@ -277,7 +290,8 @@ extern "C" int sisr_eltwise_res_affine(const float* x1, const float* slope1_p, f
 extern "C" int sisr_prelu_slope_grad(const float* dy, const float* pre, int64_t n, float* work, float* out,
                                      void* stream) {
     if (!dy || !pre || !work || !out || n <= 0) return SISR_E_BADARG;
-    const int blocks = (int)std::min<int64_t>((n + 2047) / 2048, 1024);
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(pre)) & 15) return SISR_E_BADARG;   // 16-byte loads
+    const int blocks = (int)std::min<int64_t>((n + 8191) / 8192, 1024);
     hipLaunchKernelGGL(prelu_slope_partial_kernel, dim3(blocks), dim3(SISR_BLOCK), 0, S_(stream), dy, pre, n, work);
     SISR_CHECK_LAUNCH();
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(SISR_BLOCK), 0, S_(stream), work, blocks, out);
@@ -287,7 +301,8 @@ extern "C" int sisr_prelu_slope_grad(const float* dy, const float* pre, int64_t 
 
 extern "C" int sisr_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
     if (!a || !b || !y || n <= 0) return SISR_E_BADARG;
-    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y)) & 15) return SISR_E_BADARG;
+    const int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 4096);
     hipLaunchKernelGGL(add_kernel, dim3(blocks), dim3(256), 0, S_(stream), a, b, y, n);
     SISR_CHECK_LAUNCH();
     return 0;
