@@ -122,24 +122,30 @@ __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_reduce_kernel(const SisrBnB
 }
 
 __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_finalize_kernel(const SisrBnBwdDesc d) {
-    // workgroup = 16 channels x 16 row-splits over the per-workgroup partial rows of the reduce kernel
-    __shared__ double sh1[16][16], sh2[16][16];
+    // workgroup = 4 channels x 64 row-splits over the per-workgroup partial rows of the reduce kernel: a thread
+    // sums ~grid/64 rows with independent loads (double accumulation), lanes of one channel combine by
+    // shuffles, the 4 waves through LDS -- fixed order, deterministic
+    __shared__ double sh[2][4][4];
     __shared__ float scratch[8];
     const int stride = 2 * d.C + 1;
     const double inv_n = 1.0 / (double)d.P;
-    const int cl = threadIdx.x & 15, split = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int cl = threadIdx.x & 3, split = threadIdx.x >> 2, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < d.C) {
-        for (int b = split; b < d.grid; b += 16) {
-            s1 += d.work[(int64_t)b * stride + c];
-            s2 += d.work[(int64_t)b * stride + d.C + c];
+#pragma unroll 4
+        for (int b = split; b < d.grid; b += 64) {
+            s1 += (double)d.work[(int64_t)b * stride + c];
+            s2 += (double)d.work[(int64_t)b * stride + d.C + c];
         }
     }
-    sh1[split][cl] = s1; sh2[split][cl] = s2;
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((threadIdx.x & 63) < 4) { sh[0][wave][cl] = s1; sh[1][wave][cl] = s2; }
     __syncthreads();
-    if (split == 0 && c < d.C) {
-        for (int k = 1; k < 16; ++k) { s1 += sh1[k][cl]; s2 += sh2[k][cl]; }
+    if (threadIdx.x < 4 && c < d.C) {
+        s1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
+        s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
         const float ga = d.gamma[c], is = d.invstd[c], mu = d.mean[c];
         const float qa = ga * is;
         const float qb = (float)(-(double)ga * is * is * (s2 * inv_n));
@@ -270,7 +276,7 @@ extern "C" int sisr_bn_bwd(const SisrBnBwdDesc* d, void* stream) {
     if (lds > 64 * 1024) return SISR_E_UNSUPPORTED;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(d->grid), dim3(SISR_BLOCK), lds, S_(stream), *d);
     SISR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 15) / 16), dim3(SISR_BLOCK), 0, S_(stream), *d);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 3) / 4), dim3(SISR_BLOCK), 0, S_(stream), *d);
     SISR_CHECK_LAUNCH();
     return 0;
 }
