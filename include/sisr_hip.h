@@ -59,6 +59,9 @@ typedef struct SisrConvPlan {
     int32_t wpk_elems;              /* elements in the packed weight buffer                  */
     int32_t variant;                /* bf16 family: 0 generic (chunks of 32), 1 persistent
                                        weights-resident kernel for Cin = 64 (one chunk of 64)  */
+    /* bf16 family: reciprocals m = ceil(2^32 / d) (0 for d = 1) so that n / d = umulhi(n, m) for n, d < 2^16 --
+     * the kernels' index arithmetic (tile id, tile row, LDS row) without integer division */
+    uint32_t m_tiles_x, m_thw, m_tw, m_iw, m_wrow;
 } SisrConvPlan;
 
 /* Direct convolution, fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32) accumulate.
@@ -114,6 +117,8 @@ typedef struct SisrWgradDesc {
     int32_t CK, PS, KROWP, n_chunk, CoutPad;
     int32_t NJ, NP, NT, TSTEP, TVALID;       /* co sub-tiles, pixel parts, row tiles          */
     int32_t grid_x, n_slabs, slab_elems, lds_bytes;
+    uint32_t m_tiles_x, m_tiles_y, m_iw, m_twp, m_kw;   /* bf16 kernel: reciprocals as in SisrConvPlan */
+    int32_t pad_;
     int64_t slab_stride;                     /* set by the caller after planning              */
 } SisrWgradDesc;
 

@@ -26,7 +26,8 @@ _f32 = C.c_float
 class ConvPlan(C.Structure):
     _fields_ = [(n, _i32) for n in (
         'TH', 'TW', 'TN', 'tiles_y', 'tiles_x', 'n_groups', 'n_tiles', 'CK', 'PS', 'KROWP', 'n_chunk',
-        'CoutPad', 'msub', 'nsub', 'lds_bytes', 'wpk_elems', 'variant')]
+        'CoutPad', 'msub', 'nsub', 'lds_bytes', 'wpk_elems', 'variant')] + [
+        (n, C.c_uint32) for n in ('m_tiles_x', 'm_thw', 'm_tw', 'm_iw', 'm_wrow')]
 
 
 class ConvDesc(C.Structure):
@@ -50,6 +51,7 @@ class WgradDesc(C.Structure):
                                      'CK', 'PS', 'KROWP', 'n_chunk', 'CoutPad',
                                      'NJ', 'NP', 'NT', 'TSTEP', 'TVALID',
                                      'grid_x', 'n_slabs', 'slab_elems', 'lds_bytes')] +
+                [(n, C.c_uint32) for n in ('m_tiles_x', 'm_tiles_y', 'm_iw', 'm_twp', 'm_kw')] + [('pad_', _i32)] +
                 [('slab_stride', _i64)])
 
 

@@ -28,8 +28,9 @@
 __device__ unsigned long long sisr_trace_buf[SISR_TRACE_WG * SISR_TRACE_SLOTS];
 #define TR(k)                                                                                              \
     do {                                                                                                   \
-        if (threadIdx.x == 0 && blockIdx.x < SISR_TRACE_WG && blockIdx.y == 0)                             \
-            sisr_trace_buf[blockIdx.x * SISR_TRACE_SLOTS + (k)] = wall_clock64();                          \
+        const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                          \
+        if (threadIdx.x == 0 && wg_ < SISR_TRACE_WG && blockIdx.z == 0)                                    \
+            sisr_trace_buf[wg_ * SISR_TRACE_SLOTS + (k)] = wall_clock64();                                 \
     } while (0)
 extern "C" int sisr_trace_read(void* dst, int n_u64) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sisr_trace_buf), (size_t)n_u64 * 8, 0, hipMemcpyDeviceToHost);
@@ -95,12 +96,12 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
 
     TR(0);
 #ifdef SISR_CONV_TRACE
-    if (tid == 0 && blockIdx.x < SISR_TRACE_WG && blockIdx.y == 0) {
+    if (tid == 0 && blockIdx.y * gridDim.x + blockIdx.x < SISR_TRACE_WG && blockIdx.z == 0) {
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        sisr_trace_buf[blockIdx.x * SISR_TRACE_SLOTS + 15] = ((unsigned long long)xcc << 32) | hwid;
+        sisr_trace_buf[(blockIdx.y * gridDim.x + blockIdx.x) * SISR_TRACE_SLOTS + 15] = ((unsigned long long)xcc << 32) | hwid;
     }
 #endif
     // packed weights [chunk][CoutPad][WSG] bf16: a workgroup's slice of one chunk is contiguous, 16-byte vector
@@ -114,25 +115,24 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
     const unsigned wvoff = (unsigned)tid * 16u;
     bf16x8 wv[WVEC];
     {
-        const unsigned cb = (unsigned)((blockIdx.y * BN) * WSG) * 2u;
+        const unsigned cb = (unsigned)((blockIdx.z * BN) * WSG) * 2u;
 #pragma unroll
         for (int u = 0; u < WVEC; ++u)
             if (u * SISR_BLOCK < wvecs)
                 wv[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + u * (SISR_BLOCK * 16), cb, 0));
     }
-    int t = blockIdx.x;
-    const int txi = t % p.tiles_x;
-    t /= p.tiles_x;
-    const int tyi = t % p.tiles_y, ng = t / p.tiles_y;
+    // grid = (tiles of one image group, image groups, cout tiles); index arithmetic by reciprocal multiplies
+    const int tyi = fdiv(blockIdx.x, p.m_tiles_x), txi = blockIdx.x - tyi * p.tiles_x, ng = blockIdx.y;
+    const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
     const int n0 = ng * p.TN, oy0 = tyi * p.TH, ox0 = txi * p.TW;
-    const int cout_base = blockIdx.y * BN;
+    const int cout_base = blockIdx.z * BN;
     const int thw = p.TH * p.TW, tile_rows = p.TN * thw;
 
     for (int m = tid; m < BM; m += SISR_BLOCK) {
         int off = -1;
         if (m < tile_rows) {
-            const int tn = m / thw, rem = m - tn * thw;
-            const int ty = rem / p.TW, tx = rem - ty * p.TW;
+            const int tn = fdiv(m, p.m_thw), rem = m - tn * thw;
+            const int ty = fdiv(rem, p.m_tw), tx = rem - ty * p.TW;
             const int n = n0 + tn, oy = oy0 + ty, ox = ox0 + tx;
             if (n < d.N && oy < d.Ho && ox < d.Wo) {
                 const int py = oy * d.y_sy + d.y_oy, px = ox * d.y_sx + d.y_ox;
@@ -155,8 +155,8 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
         const int m = wave * (MSUB * 32) + ms * 32 + l31;
         int base = 0;
         if (m < tile_rows) {
-            const int tn = m / thw, rem = m - tn * thw;
-            const int ty = rem / p.TW, tx = rem - ty * p.TW;
+            const int tn = fdiv(m, p.m_thw), rem = m - tn * thw;
+            const int ty = fdiv(rem, p.m_tw), tx = rem - ty * p.TW;
             base = ((tn * IH + ty * S) * IW + tx * S) * BF_PS;
         }
         ap[ms] = lds_in + base + 8 * kk;
@@ -179,14 +179,14 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
     ov.mode = d.x_mode; ov.pro = d.pro_mode;
     ov.slope = d.pro_slope_p ? d.pro_slope_p[0] : d.pro_slope;
     const int iy_org = oy0 * S - d.pad_y, ix_org = ox0 * S - d.pad_x;
-    const int wstep_j = SISR_BLOCK / wvec_row, wstep_k = SISR_BLOCK - wstep_j * wvec_row;
+    const int wstep_j = fdiv(SISR_BLOCK, p.m_wrow), wstep_k = SISR_BLOCK - wstep_j * wvec_row;
     const int wstep_off = wstep_j * WS + wstep_k * 8;
-    const int wk0 = tid % wvec_row, woff0 = (tid / wvec_row) * WS + wk0 * 8;
+    const int wj0 = fdiv(tid, p.m_wrow), wk0 = tid - wj0 * wvec_row, woff0 = wj0 * WS + wk0 * 8;
 
     for (int chunk = 0; chunk < p.n_chunk; ++chunk) {
         __syncthreads();   // all fragment reads of the previous chunk are done
         TR(1 + 4 * (chunk & 1));
-        stage_operand_tile_bf16(ov, lds_in, BF_PS, BF_CK, chunk * BF_CK, p.TN, IH, IW, n0, iy_org, ix_org, 1 << 30);
+        stage_operand_tile_bf16(ov, lds_in, BF_PS, BF_CK, chunk * BF_CK, p.TN, IH, IW, n0, iy_org, ix_org, 1 << 30, p.m_iw);
         TR(2 + 4 * (chunk & 1));
         {   // this chunk's packed weights are already in registers (loaded during the previous MFMA phase / the
             // kernel prologue): write them to LDS, then put the next chunk's loads in flight
@@ -295,10 +295,10 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
                 const float* r = red + (w * BN + tid) * 3;
                 stat_merge(nn, mu, m2, r[0], r[1], r[2]);
             }
-            float* sp = d.stat_part + (int64_t)blockIdx.x * 2 * d.Cout + cout_base + tid;
+            float* sp = d.stat_part + (int64_t)tile_id * 2 * d.Cout + cout_base + tid;
             sp[0] = mu;
             sp[d.Cout] = m2;
-            if (tid == 0 && blockIdx.y == 0) d.cnt_part[blockIdx.x] = nn;
+            if (tid == 0 && blockIdx.z == 0) d.cnt_part[tile_id] = nn;
         }
     }
     TR(11);
@@ -413,6 +413,12 @@ extern "C" int sisr_conv2d_plan_bf16(SisrConvDesc* d) {
     if (cand_cost[pick] > 1e29) return SISR_E_TOOBIG;
     p = cand[pick];
     p.n_tiles = p.tiles_y * p.tiles_x * p.n_groups;
+    if (p.tiles_y * p.tiles_x >= 65536 || p.n_groups >= 65536) return SISR_E_TOOBIG;   // grid (x, y) and reciprocal range
+    {
+        const int IW = (p.TW - 1) * S + d->KW;
+        p.m_tiles_x = fdiv_magic(p.tiles_x); p.m_thw = fdiv_magic(p.TH * p.TW); p.m_tw = fdiv_magic(p.TW);
+        p.m_iw = fdiv_magic(IW); p.m_wrow = fdiv_magic(d->KH * d->KW * BF_CK / 8);
+    }
     p.lds_bytes = cand_lds[pick];
     p.wpk_elems = p.n_chunk * p.CoutPad * p.KROWP;       // bf16 elements
     return 0;
@@ -427,7 +433,7 @@ static int launch_conv_bf16(const SisrConvDesc* d, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         lds_max = d->plan.lds_bytes;
     }
-    const dim3 grid(d->plan.n_tiles, d->plan.CoutPad / (NSUB * 32));
+    const dim3 grid(d->plan.tiles_x * d->plan.tiles_y, d->plan.n_groups, d->plan.CoutPad / (NSUB * 32));
     hipLaunchKernelGGL((conv_mfma_bf16_kernel<MSUB, NSUB, TAG>), grid, dim3(SISR_BLOCK), d->plan.lds_bytes, st, *d);
     SISR_CHECK_LAUNCH();
     return 0;

@@ -19,7 +19,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_rsrc(const void* p, unsigne
 // which the hardware answers with zeros -- no divergent branch, no 64-bit address math, no multiplies.
 template <int PRO, int SBQ>
 __device__ __forceinline__ void stage_tile_bf16(const OperandView& o, __bf16* lds, int PS, int CK, int c0, int TN,
-                                                int IH, int IW, int n0, int iy_org, int ix_org, int valid_w) {
+                                                int IH, int IW, int n0, int iy_org, int ix_org, int valid_w,
+                                                uint32_t m_iw) {
     constexpr bool need2 = PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD || PRO == SISR_PRO_ACT_BWD ||
                            PRO == SISR_PRO_TANH_BWD;
     // prologues with f(0) != 0 need the halo forced to zero after the transform
@@ -59,11 +60,11 @@ __device__ __forceinline__ void stage_tile_bf16(const OperandView& o, __bf16* ld
 
     constexpr int SB = need2 ? SBQ / 2 : SBQ;      // loads in flight per thread and operand
     const int ppi = SISR_BLOCK >> lg;              // pixels advanced per item step
-    const int step_rows = ppi / IW, step_cols = ppi - step_rows * IW;
+    const int step_rows = fdiv(ppi, m_iw), step_cols = ppi - step_rows * IW;      // m_iw = fdiv_magic(IW)
     const int npix = TN * IH * IW;
     const int d_roff = step_rows * row_step, d_xoff = step_cols * col_step, wrap_xoff = IW * col_step;
     int pix = tid >> lg;
-    int row = pix / IW, ixl = pix - row * IW;
+    int row = fdiv(pix, m_iw), ixl = pix - row * IW;
     int roff = row * row_step, xoff = ixl * col_step;
     __bf16* dst = lds + pix * PS + g * 4;
     const int dst_step = ppi * PS;
@@ -109,10 +110,10 @@ __device__ __forceinline__ void stage_tile_bf16(const OperandView& o, __bf16* ld
 template <int SBQ = 8>
 __device__ __forceinline__ void stage_operand_tile_bf16(const OperandView& o, __bf16* lds, int PS, int CK, int c0,
                                                         int TN, int IH, int IW, int n0, int iy_org, int ix_org,
-                                                        int valid_w) {
+                                                        int valid_w, uint32_t m_iw) {
     switch (o.pro) {
 #define SISR_STAGE_CASE(P) \
-    case P: stage_tile_bf16<P, SBQ>(o, lds, PS, CK, c0, TN, IH, IW, n0, iy_org, ix_org, valid_w); break;
+    case P: stage_tile_bf16<P, SBQ>(o, lds, PS, CK, c0, TN, IH, IW, n0, iy_org, ix_org, valid_w, m_iw); break;
         SISR_STAGE_CASE(SISR_PRO_NONE)
         SISR_STAGE_CASE(SISR_PRO_ACT)
         SISR_STAGE_CASE(SISR_PRO_AFFINE_ACT)

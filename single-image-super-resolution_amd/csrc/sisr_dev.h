@@ -46,6 +46,13 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
     return t;
 }
 
+// n / d for n, d < 2^16 with the host-side reciprocal m = ceil(2^32 / d) (0 encodes d = 1): one multiply-high
+// instead of the ~25-instruction integer division sequence
+__host__ __device__ __forceinline__ uint32_t fdiv_magic(int d) {
+    return d <= 1 ? 0u : (uint32_t)((0x100000000ull + (uint32_t)d - 1) / (uint32_t)d);
+}
+__device__ __forceinline__ int fdiv(int n, uint32_t m) { return m ? (int)__umulhi((unsigned)n, m) : n; }
+
 // One input element of a (possibly lazily transformed) operand; see SISR_PRO_* in sisr_hip.h.
 struct OperandView {
     const float *x1, *x2, *pa, *pb, *pd, *ps, *pt;

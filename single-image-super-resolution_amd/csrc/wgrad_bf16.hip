@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
     const int npix_in = d.TN * IH * IW;
     const int DCH = d.NJ * 32, DS = wg_dy_stride(DCH);
     const int ntap = d.KH * d.KW;
-    const int jsub = wave % d.NJ, tpart = wave / d.NJ;
+    const int jsub = wave & (d.NJ - 1), tpart = wave >> (d.NJ >> 1);          // NJ is 1 or 2
     const int tap0 = tpart * TPW;
     const int q = blockIdx.y % d.n_chunk, cot = blockIdx.y / d.n_chunk;
     const int co_base = cot * DCH;
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
 #pragma unroll
     for (int a = 0; a < TPW; ++a) {
         const int tap = min(tap0 + a, ntap - 1);
-        const int r = tap / d.KW, s = tap - r * d.KW;
+        const int r = fdiv(tap, d.m_kw), s = tap - r * d.KW;
         aoff[a] = (r * IW + s) * WG_PSX;
     }
     f32x16 acc[TPW];
@@ -116,24 +116,23 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
     const int a2 = 4 * S * WG_PSX, b2 = 4 * DS;
 
     for (int t = blockIdx.x; t < d.n_tiles; t += gridDim.x, ++titer) {
-        int tt_ = t;
-        const int txi = tt_ % d.tiles_x;
-        tt_ /= d.tiles_x;
-        const int tyi = tt_ % d.tiles_y, ng = tt_ / d.tiles_y;
+        const int trow = fdiv(t, d.m_tiles_x), txi = t - trow * d.tiles_x;       // t < 2^16 (planner)
+        const int ng = fdiv(trow, d.m_tiles_y), tyi = trow - ng * d.tiles_y;
         const int n0 = ng * d.TN, oy0 = tyi * d.TH, ox0 = txi * d.TW;
         __syncthreads();   // previous tile fully consumed
         WTR(1 + 5 * titer);
         stage_operand_tile_bf16<8>(ox, lds_in, WG_PSX, BF_CK, q * BF_CK, d.TN, IH, IW, n0, oy0 * S - d.pad_y,
-                                ox0 * S - d.pad_x, 1 << 30);
+                                ox0 * S - d.pad_x, 1 << 30, d.m_iw);
         WTR(2 + 5 * titer);
-        stage_operand_tile_bf16<8>(og, lds_dy, DS, DCH, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, d.TW);
+        stage_operand_tile_bf16<8>(og, lds_dy, DS, DCH, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, d.TW, d.m_twp);
         WTR(3 + 5 * titer);
         __syncthreads();
         WTR(4 + 5 * titer);
         if (d.bias_slab != nullptr && q == 0) {
             // bias-gradient partial: every thread sums a strided share of the tile's pixels for one channel
             // (all 256 threads, independent loads) -- combined across the pixel shares after the tile loop
-            const int co = tid % DCH, share = tid / DCH, nshare = SISR_BLOCK / DCH;
+            const int lgd = d.NJ == 2 ? 6 : 5;                       // DCH = 32 * NJ
+            const int co = tid & (DCH - 1), share = tid >> lgd, nshare = SISR_BLOCK >> lgd;
             const int npx = d.TN * d.TH * TWp;
             float s = 0.f;
 #pragma unroll 8
@@ -257,6 +256,12 @@ extern "C" int sisr_wgrad_plan_bf16(SisrWgradDesc* d, int32_t max_pixel_blocks) 
     }
     if (best < 0) return SISR_E_TOOBIG;
     d->n_tiles = d->tiles_y * d->tiles_x * d->n_groups;
+    if (d->n_tiles >= 65536) return SISR_E_TOOBIG;          // range of the reciprocal index arithmetic
+    {
+        const int TWp = (d->TW + 15) & ~15;
+        d->m_tiles_x = fdiv_magic(d->tiles_x); d->m_tiles_y = fdiv_magic(d->tiles_y);
+        d->m_iw = fdiv_magic((TWp - 1) * S + d->KW); d->m_twp = fdiv_magic(TWp); d->m_kw = fdiv_magic(d->KW);
+    }
     d->grid_x = std::min(gx_max, d->n_tiles);
     d->n_slabs = d->grid_x;
     d->slab_elems = d->n_chunk * d->KROWP * d->CoutPad;
