@@ -15,16 +15,18 @@
 // Workgroup = 4 channels x 256 tile-splits (1024 threads): C/4 workgroups, a few tiles per thread.
 #define BNF_SPLITS 256
 #define BNF_CH 4
-__device__ __forceinline__ double bnf_reduce(double v, double (*sh)[BNF_CH], int split, int cl) {
-    sh[split][cl] = v;
+// sum over the 256 tile-splits of each of the 4 channels: lanes of one channel combine by shuffles (thread =
+// channel + 4 * split, so a wave holds 16 splits of every channel), the 16 waves through LDS; fixed order
+__device__ __forceinline__ void bnf_reduce2(double& a, double& b, double (*sh)[2][BNF_CH], int cl) {
+#pragma unroll
+    for (int o = BNF_CH; o < 64; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                                   // previous use of sh is over
+    if ((threadIdx.x & 63) < BNF_CH) { sh[wave][0][cl] = a; sh[wave][1][cl] = b; }
     __syncthreads();
-    for (int half = BNF_SPLITS / 2; half >= 1; half >>= 1) {
-        if (split < half) sh[split][cl] += sh[split + half][cl];
-        __syncthreads();
-    }
-    const double r = sh[0][cl];
-    __syncthreads();
-    return r;
+    a = 0.0; b = 0.0;
+#pragma unroll
+    for (int w = 0; w < (BNF_SPLITS * BNF_CH) / 64; ++w) { a += sh[w][0][cl]; b += sh[w][1][cl]; }
 }
 
 __global__ void __launch_bounds__(1024) bn_finalize_kernel(
@@ -32,7 +34,7 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
     float* save_invstd) {
-    __shared__ double sh[BNF_SPLITS][BNF_CH];
+    __shared__ double sh[(BNF_SPLITS * BNF_CH) / 64][2][BNF_CH];
     const int cl = threadIdx.x & (BNF_CH - 1), split = threadIdx.x / BNF_CH;
     const int c = min(blockIdx.x * BNF_CH + cl, C - 1);
     double n = 0.0, s = 0.0;
@@ -41,15 +43,15 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(
         n += nb;
         s += nb * (double)stat_part[(int64_t)t * 2 * C + c];
     }
-    n = bnf_reduce(n, sh, split, cl);
-    const double mean = bnf_reduce(s, sh, split, cl) / n;
-    double m2 = 0.0;
+    bnf_reduce2(n, s, sh, cl);
+    const double mean = s / n;
+    double m2 = 0.0, unused = 0.0;
     for (int t = split; t < n_tiles; t += BNF_SPLITS) {
         const double nb = cnt_part[t];
         const double dm = (double)stat_part[(int64_t)t * 2 * C + c] - mean;
         m2 += (double)stat_part[(int64_t)t * 2 * C + C + c] + nb * dm * dm;
     }
-    m2 = bnf_reduce(m2, sh, split, cl);
+    bnf_reduce2(m2, unused, sh, cl);
     if (split == 0 && blockIdx.x * BNF_CH + cl < C) {
         const double var = m2 / n;                       // biased (normalisation)
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
