@@ -78,6 +78,13 @@ typedef struct SisrConvDesc {
     float *y;
     float *stat_part;                        /* [n_tiles][2][Cout] (mean, M2) or NULL         */
     float *cnt_part;                         /* [n_tiles] valid pixels per tile               */
+    /* bf16 kernels, NHWC output: the output y is the gradient g arriving at a BatchNorm (optionally through the
+     * leaky activation after it); the epilogue then also emits that BatchNorm's backward reductions per tile --
+     * bnb_part[tile][0..C) = sum gg, [C..2C) = sum gg*xhat, [2C] = sum_{z<=0} g*z  (gg = act'(z)*g,
+     * z = scale*x + shift, xhat = (x - mean)*invstd) -- in the row format sisr_bn_bwd_finalize reads.  NULL: off. */
+    const float *bnb_x, *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
+    const float *bnb_slope_p;
+    float *bnb_part;
     int32_t N, H, W, Cin;                    /* logical input                                 */
     int32_t Ho, Wo, Cout;                    /* logical output grid                           */
     int32_t KH, KW, stride, pad_y, pad_x;
@@ -85,6 +92,7 @@ typedef struct SisrConvDesc {
     const float *pro_slope_p;                /* device scalar slope (PReLU weight); NULL: pro_slope */
     float pro_slope;
     int32_t y_mode, epi_act;
+    int32_t bnb_act; float bnb_slope;        /* activation after that BatchNorm: 0 none, 1 leaky (slope / *slope_p) */
     int32_t y_sy, y_oy, y_sx, y_ox, y_H, y_W; /* output pixel (oy*y_sy+y_oy, ox*y_sx+y_ox) of a
                                                 y_H x y_W image (strided scatter for the data
                                                 gradient of stride-2 convs); plain: 1,0,1,0,Ho,Wo */
@@ -217,6 +225,8 @@ typedef struct SisrBnBwdDesc {
 } SisrBnBwdDesc;
 int sisr_bn_bwd_plan(SisrBnBwdDesc *d);
 int sisr_bn_bwd(const SisrBnBwdDesc *d, void *stream);
+/* second half only: `work` holds d->grid partial rows [2*C+1] written by a conv epilogue (SisrConvDesc.bnb_part) */
+int sisr_bn_bwd_finalize(const SisrBnBwdDesc *d, void *stream);
 
 /* elementwise: y = f(x1) + (pa ? pa[c]*x2 + pd[c] : x2)   over NHWC [P][C];
  * f = lrelu(., slope1_p ? *slope1_p : slope1) -- the residual add of BasicBlock.forward (model_generator.py:19) and the

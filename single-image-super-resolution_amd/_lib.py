@@ -32,11 +32,13 @@ class ConvPlan(C.Structure):
 
 class ConvDesc(C.Structure):
     _fields_ = ([(n, _f) for n in ('x1', 'x2', 'pa', 'pb', 'pd', 'ps', 'pt', 'wpk', 'bias', 'res', 'y',
-                                   'stat_part', 'cnt_part')] +
+                                   'stat_part', 'cnt_part', 'bnb_x', 'bnb_scale', 'bnb_shift', 'bnb_mean',
+                                   'bnb_invstd', 'bnb_slope_p', 'bnb_part')] +
                 [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride',
                                      'pad_y', 'pad_x', 'x_mode', 'pro_mode')] +
                 [('pro_slope_p', _f), ('pro_slope', _f32)] +
-                [(n, _i32) for n in ('y_mode', 'epi_act', 'y_sy', 'y_oy', 'y_sx', 'y_ox', 'y_H', 'y_W')] +
+                [('y_mode', _i32), ('epi_act', _i32), ('bnb_act', _i32), ('bnb_slope', _f32)] +
+                [(n, _i32) for n in ('y_sy', 'y_oy', 'y_sx', 'y_ox', 'y_H', 'y_W')] +
                 [('plan', ConvPlan)])
 
 
@@ -98,6 +100,7 @@ _SIGS = {
     'sisr_bn_eval_consts': [_f, _f, _f, _f, _f32, _i32, _f, _f, _f],
     'sisr_bn_bwd_plan': [C.POINTER(BnBwdDesc)],
     'sisr_bn_bwd': [C.POINTER(BnBwdDesc), _f],
+    'sisr_bn_bwd_finalize': [C.POINTER(BnBwdDesc), _f],
     'sisr_eltwise_res_affine': [_f, _f, _f32, _f, _f, _f, _f, _i64, _i32, _f],
     'sisr_prelu_slope_grad': [_f, _f, _i64, _f, _f, _f],
     'sisr_add': [_f, _f, _f, _i64, _f],

@@ -306,6 +306,21 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
     // output (and residual) through raw buffer accesses with 32-bit byte offsets
     const unsigned ybytes = (unsigned)max(d.N * d.y_H * d.y_W, d.N * d.Ho * d.Wo) * (unsigned)d.Cout * 4u;
     const __amdgpu_buffer_rsrc_t ry = bf_rsrc(d.y, ybytes);
+    // fused BatchNorm-backward reductions (below): that BatchNorm's input at this lane's pixels, requested before
+    // the residual so both sets of loads share one memory latency
+    float bx[MSUB][NSUB][16];
+    if (d.bnb_part != nullptr) {
+        const __amdgpu_buffer_rsrc_t rx = bf_rsrc(d.bnb_x, ybytes);
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+            for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const unsigned vo = col_ok[ns] ? rb[ms][i] + (unsigned)col_off[ns] * 4u : 0x80000000u;
+                    bx[ms][ns][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vo, 0, 0));
+                }
+    }
     if (d.res != nullptr) {
         const __amdgpu_buffer_rsrc_t rr = bf_rsrc(d.res, ybytes);
 #pragma unroll
@@ -317,6 +332,48 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
                     for (int i = 0; i < 16; ++i)
                         acc[ms][ns][i] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, rb[ms][i] + (unsigned)col_off[ns] * 4u, 0, 0));
             }
+    }
+    if (d.bnb_part != nullptr) {
+        // BatchNorm-backward reductions of the gradient tile just formed (y + residual), see SisrConvDesc.bnb_*:
+        // per lane over its rows, lane halves by a shuffle, the 4 waves through LDS (fixed order)
+        const float bslope = d.bnb_slope_p ? d.bnb_slope_p[0] : d.bnb_slope;
+        float ssl = 0.f;
+        __syncthreads();                                   // `red` may still hold the forward statistics
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+            const int cp = cout_base + ns * 32 + l31;
+            float sc = 0.f, sf = 0.f, mu = 0.f, is = 0.f;
+            if (col_ok[ns]) { sc = d.bnb_scale[cp]; sf = d.bnb_shift[cp]; mu = d.bnb_mean[cp]; is = d.bnb_invstd[cp]; }
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float xv = bx[ms][ns][i];
+                    float g = rv[ms][i] ? (float)acc[ms][ns][i] : 0.f;
+                    if (d.bnb_act) {
+                        const float z = sc * xv + sf;
+                        if (!(z > 0.f)) { ssl += g * z; g *= bslope; }
+                    }
+                    s1 += g;
+                    s2 += g * ((xv - mu) * is);
+                }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (kk == 0) { red[(wave * BN + ns * 32 + l31) * 2] = s1; red[(wave * BN + ns * 32 + l31) * 2 + 1] = s2; }
+        }
+        ssl = wave_sum(ssl);
+        if (lane == 0) red[8 * BN + wave] = ssl;
+        __syncthreads();
+        float* wk = d.bnb_part + (int64_t)tile_id * (2 * d.Cout + 1);
+        if (tid < BN && cout_base + tid < d.Cout) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s1 += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
+            wk[cout_base + tid] = s1;
+            wk[d.Cout + cout_base + tid] = s2;
+        }
+        if (tid == 0 && blockIdx.z == 0) wk[2 * d.Cout] = red[8 * BN] + red[8 * BN + 1] + red[8 * BN + 2] + red[8 * BN + 3];
     }
     if (d.epi_act == SISR_EPI_TANH) {
 #pragma unroll
@@ -444,6 +501,10 @@ extern "C" int sisr_conv2d_bf16(const SisrConvDesc* d, void* stream) {
     if (d->plan.variant == 1) return sisr_conv2d_bf16_persist(d, stream);
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
     if (d->stat_part && (!d->cnt_part || d->y_mode != SISR_Y_NHWC)) return SISR_E_BADARG;
+    if (d->bnb_part && (d->y_mode != SISR_Y_NHWC || d->y_sy != 1 || d->y_sx != 1 || d->y_H != d->Ho || d->y_W != d->Wo ||
+                        !d->bnb_x || !d->bnb_scale || !d->bnb_shift || !d->bnb_mean || !d->bnb_invstd ||
+                        d->epi_act != SISR_EPI_NONE || d->plan.CoutPad / (d->plan.nsub * 32) != 1))
+        return SISR_E_UNSUPPORTED;
     const SisrConvPlan& p = d->plan;
     if (d->x_mode == SISR_X_NCHW || (d->Cin % BF_CK) || (d->x_mode == SISR_X_NHWC_UNSHUFFLE2 && ((d->Cin >> 2) & 3)))
         return SISR_E_UNSUPPORTED;

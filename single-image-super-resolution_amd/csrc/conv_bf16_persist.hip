@@ -445,6 +445,7 @@ static int launch_pc(const SisrConvDesc* d, hipStream_t st) {
 }
 
 extern "C" int sisr_conv2d_bf16_persist(const SisrConvDesc* d, void* stream) {
+    if (d && d->bnb_part) return SISR_E_UNSUPPORTED;     // fused BatchNorm-backward partials: generic bf16 kernel only
     if (!d || !d->x1 || !d->wpk || !d->y || d->plan.variant != 1) return SISR_E_BADARG;
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
     if (d->stat_part && (!d->cnt_part || d->y_mode != SISR_Y_NHWC)) return SISR_E_BADARG;

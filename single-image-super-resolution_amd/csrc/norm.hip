@@ -283,6 +283,15 @@ extern "C" int sisr_bn_bwd(const SisrBnBwdDesc* d, void* stream) {
     return 0;
 }
 
+extern "C" int sisr_bn_bwd_finalize(const SisrBnBwdDesc* d, void* stream) {
+    if (!d || !d->invstd || !d->mean || !d->gamma || !d->work || !d->qa || !d->qb || !d->qd || !d->dgamma || !d->dbeta ||
+        d->grid <= 0 || d->C <= 0 || d->P <= 0)
+        return SISR_E_BADARG;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 3) / 4), dim3(SISR_BLOCK), 0, S_(stream), *d);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sisr_eltwise_res_affine(const float* x1, const float* slope1_p, float slope1, const float* x2,
                                        const float* pa, const float* pd, float* y, int64_t P, int32_t C,
                                        void* stream) {

@@ -330,8 +330,18 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
     return out, sp, cp
 
 
-def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC):
-    """Data gradient: conv over the (lazy) output gradient with the flipped packed weights."""
+def can_fuse_bn_backward(prep):
+    """the data-gradient conv of `prep` can also emit the backward reductions of the BatchNorm its output feeds
+    (generic bf16 kernel, one cout tile)"""
+    d = prep.plans[1]
+    return (not isinstance(d, list)) and d is not None and bool(prep.kinds[1]) and d.plan.variant == 0 and \
+        d.plan.CoutPad == d.plan.nsub * 32
+
+
+def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
+    """Data gradient: conv over the (lazy) output gradient with the flipped packed weights.
+    bnb = (x, consts [4,C], slope | None): the result is the gradient arriving at BatchNorm(x) (through a leaky
+    activation when slope is given); returns (out, partial rows for bn_backward_finalize) in that case."""
     lib = L.lib()
     gm = prep.ref.geom
     if isinstance(prep.plans[1], list):          # stride 2: four output-parity classes
@@ -359,11 +369,24 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC):
         out = torch.empty((d.N, d.Ho, d.Wo, gm.cin), dtype=torch.float32, device=dev)
     dy_op.fill(d)
     d.wpk, d.bias, d.res, d.y = prep.wpk_dgrad.data_ptr(), None, _ptr(res), out.data_ptr()
+    part = None
+    if bnb is not None:
+        x, consts, slope = bnb
+        assert tuple(x.shape) == tuple(out.shape) and y_mode == L.Y_NHWC
+        part = torch.empty((d.plan.n_tiles, 2 * gm.cin + 1), dtype=torch.float32, device=dev)
+        d.bnb_x, d.bnb_part = x.data_ptr(), part.data_ptr()
+        d.bnb_scale, d.bnb_shift, d.bnb_mean, d.bnb_invstd = (consts[0].data_ptr(), consts[1].data_ptr(),
+                                                              consts[2].data_ptr(), consts[3].data_ptr())
+        d.bnb_act = 0 if slope is None else 1
+        if isinstance(slope, torch.Tensor):
+            d.bnb_slope_p, d.bnb_slope = slope.data_ptr(), 1.0
+        else:
+            d.bnb_slope_p, d.bnb_slope = None, 1.0 if slope is None else float(slope)
     if prep.kinds[1]:
         L.check(lib.sisr_conv2d_bf16(C.byref(d), _stream()), 'sisr_conv2d_bf16(dgrad)')
     else:
         L.check(lib.sisr_conv2d_f32(C.byref(d), _stream()), 'sisr_conv2d_f32(dgrad)')
-    return out
+    return out if bnb is None else (out, part)
 
 
 def conv_wgrad(prep, x_op, dy_op):
@@ -459,9 +482,10 @@ def bn_eval_consts(bn, eps=1e-5):
     return k
 
 
-def bn_backward(dy, x, consts, gamma, slope=None):
+def bn_backward(dy, x, consts, gamma, slope=None, part=None):
     """Reductions of BatchNorm backward (+ the leaky activation after it when slope is given).
-    Returns (q [3,C] = qa,qb,qd ; dgamma ; dbeta ; dslope or None)."""
+    Returns (q [3,C] = qa,qb,qd ; dgamma ; dbeta ; dslope or None).  part: per-tile partial rows already written
+    by the conv that produced dy (conv_dgrad(..., bnb=...)); only the finishing kernel runs then."""
     lib = L.lib()
     cch = x.shape[-1]
     d = L.BnBwdDesc()
@@ -471,9 +495,12 @@ def bn_backward(dy, x, consts, gamma, slope=None):
         d.slope_p, d.slope = slope.data_ptr(), 1.0
     else:
         d.slope_p, d.slope = None, 1.0 if slope is None else float(slope)
-    L.check(lib.sisr_bn_bwd_plan(C.byref(d)), 'sisr_bn_bwd_plan')
     dev = x.device
-    work = torch.empty((d.grid, 2 * cch + 1), dtype=torch.float32, device=dev)
+    if part is None:
+        L.check(lib.sisr_bn_bwd_plan(C.byref(d)), 'sisr_bn_bwd_plan')
+        work = torch.empty((d.grid, 2 * cch + 1), dtype=torch.float32, device=dev)
+    else:
+        work, d.grid = part, part.shape[0]
     q = torch.empty((3, cch), dtype=torch.float32, device=dev)
     dgamma = torch.empty((cch,), dtype=torch.float32, device=dev)
     dbeta = torch.empty((cch,), dtype=torch.float32, device=dev)
@@ -484,7 +511,10 @@ def bn_backward(dy, x, consts, gamma, slope=None):
     d.gamma, d.work = gamma.data_ptr(), work.data_ptr()
     d.qa, d.qb, d.qd = q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr()
     d.dgamma, d.dbeta, d.dslope = dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dslope)
-    L.check(lib.sisr_bn_bwd(C.byref(d), _stream()), 'sisr_bn_bwd')
+    if part is None:
+        L.check(lib.sisr_bn_bwd(C.byref(d), _stream()), 'sisr_bn_bwd')
+    else:
+        L.check(lib.sisr_bn_bwd_finalize(C.byref(d), _stream()), 'sisr_bn_bwd_finalize')
     return q, dgamma, dbeta, dslope
 
 

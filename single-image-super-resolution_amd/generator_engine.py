@@ -138,12 +138,21 @@ def run_backward(sv, grad_out, need_dx):
     grads = {}
     wg = E.WeightGradBatch()
 
-    def conv_bwd(ref, x_op, dy_op, need_dgrad=True, res=None, y_mode=L.Y_NHWC):
+    def conv_bwd(ref, x_op, dy_op, need_dgrad=True, res=None, y_mode=L.Y_NHWC, bnb=None):
+        """weight gradient (batched un-packing at the end) + data gradient.  bnb = (x, consts, slope) names the
+        BatchNorm the data gradient arrives at: where the conv kernel can, it emits that BatchNorm's backward
+        reductions from its epilogue and (gradient, partial rows) is returned instead of the gradient."""
         p = P[id(ref)]
         want_w, want_b = ref.weight.requires_grad, ref.bias is not None and ref.bias.requires_grad
         if want_w or want_b:
             wg.add(p, E.conv_wgrad(p, x_op, dy_op), want_w, want_b)
-        return E.conv_dgrad(p, dy_op, res=res, y_mode=y_mode) if need_dgrad else None
+        if not need_dgrad:
+            return None
+        if bnb is None:
+            return E.conv_dgrad(p, dy_op, res=res, y_mode=y_mode)
+        if E.can_fuse_bn_backward(p):
+            return E.conv_dgrad(p, dy_op, res=res, y_mode=y_mode, bnb=bnb)
+        return E.conv_dgrad(p, dy_op, res=res, y_mode=y_mode), None
 
     n = sv.x.shape[0]
     # ---- end conv + tanh (or, for forward_no_end, the NCHW -> NHWC change of the incoming gradient) --------
@@ -156,6 +165,7 @@ def run_backward(sv, grad_out, need_dx):
         dy = Operand(grad_out, (n, ho, wo, sv.out.shape[1]), pro=L.PRO_TANH_BWD, mode=L.X_NCHW, x2=sv.out)
         g = conv_bwd(topo.end, sv.end_in, dy)              # grad wrt the (activated) input of `end`
     # ---- upscale stages, last to first ---------------------------------------------------------------
+    part = None
     for k in range(len(topo.stages) - 1, -1, -1):
         ref, slope = topo.stages[k]
         pre = sv.stage_pre[k]
@@ -163,29 +173,43 @@ def run_backward(sv, grad_out, need_dx):
             grads[id(slope)] = E.prelu_slope_grad(g, pre)
         hk, wk, cq = pre.shape[1] // 2, pre.shape[2] // 2, pre.shape[3]
         dy = Operand(g, (n, hk, wk, 4 * cq), pro=L.PRO_ACT_BWD, mode=L.X_UNSHUFFLE2, x2=pre, slope=slope)
-        g = conv_bwd(ref, sv.stage_in[k], dy)
+        if k == 0:                                          # its data gradient arrives at the trunk's BatchNorm
+            g, part = conv_bwd(ref, sv.stage_in[k], dy, bnb=(sv.ce, sv.ke, None))
+        else:
+            g = conv_bwd(ref, sv.stage_in[k], dy)
     # ---- trunk end: conv + BN (+ long skip) ----------------------------------------------------------
     g_t = g                                               # grad wrt BN_e output (and wrt t0 via the skip)
     bn = topo.trunk_bn
-    q, dgam, dbet, _ = E.bn_backward(g_t, sv.ce, sv.ke, bn.weight)
+    q, dgam, dbet, _ = E.bn_backward(g_t, sv.ce, sv.ke, bn.weight, part=part)
     grads[id(bn.weight)], grads[id(bn.bias)] = dgam, dbet
     dy = Operand(g_t, tuple(sv.ce.shape), pro=L.PRO_BNBWD, x2=sv.ce, pa=q[0], pb=q[1], pd=q[2])
     xl_op = Operand.act(sv.xl_raw, sv.xl_slope) if sv.xl_slope is not None else Operand.plain(sv.xl_raw)
-    g = conv_bwd(topo.trunk_end, xl_op, dy)
+    # every data gradient below arrives at the next BatchNorm of the chain (conv_bwd's bnb): that BatchNorm's
+    # two backward reductions come out of the producing conv's epilogue, not out of a pass of their own
+    rblocks = list(zip(reversed(topo.blocks), reversed(sv.blocks)))
+    if rblocks:
+        g, part = conv_bwd(topo.trunk_end, xl_op, dy, bnb=(rblocks[0][1].c2, rblocks[0][1].k2, None))
+    else:
+        g = conv_bwd(topo.trunk_end, xl_op, dy)
     # ---- residual blocks, last to first ----------------------------------------------------------------
-    for b, rec in zip(reversed(topo.blocks), reversed(sv.blocks)):
-        q2, dgam, dbet, _ = E.bn_backward(g, rec.c2, rec.k2, b['bn2'].weight)
+    for bi, (b, rec) in enumerate(rblocks):
+        q2, dgam, dbet, _ = E.bn_backward(g, rec.c2, rec.k2, b['bn2'].weight, part=part)
         grads[id(b['bn2'].weight)], grads[id(b['bn2'].bias)] = dgam, dbet
         dy2 = Operand(g, tuple(rec.c2.shape), pro=L.PRO_BNBWD, x2=rec.c2, pa=q2[0], pb=q2[1], pd=q2[2])
         a1_op = Operand.affine_act(rec.c1, rec.k1[0], rec.k1[1], b['prelu'])
-        g_a1 = conv_bwd(b['c2'], a1_op, dy2)
-        q1, dgam, dbet, dsl = E.bn_backward(g_a1, rec.c1, rec.k1, b['bn1'].weight, slope=b['prelu'])
+        g_a1, part = conv_bwd(b['c2'], a1_op, dy2, bnb=(rec.c1, rec.k1, b['prelu']))
+        q1, dgam, dbet, dsl = E.bn_backward(g_a1, rec.c1, rec.k1, b['bn1'].weight, slope=b['prelu'], part=part)
         grads[id(b['bn1'].weight)], grads[id(b['bn1'].bias)] = dgam, dbet
         grads[id(b['prelu'])] = dsl
         dy1 = Operand(g_a1, tuple(rec.c1.shape), pro=L.PRO_BNACT_BWD, x2=rec.c1, pa=q1[0], pb=q1[1],
                       pd=q1[2], ps=rec.k1[0], pt=rec.k1[1], slope=b['prelu'])
         in_op = Operand.act(rec.in_raw, rec.in_slope) if rec.in_slope is not None else Operand.plain(rec.in_raw)
-        g = conv_bwd(b['c1'], in_op, dy1, res=g)          # + skip gradient, fused in the epilogue
+        # + skip gradient, fused in the epilogue
+        if bi + 1 < len(rblocks):
+            nrec = rblocks[bi + 1][1]
+            g, part = conv_bwd(b['c1'], in_op, dy1, res=g, bnb=(nrec.c2, nrec.k2, None))
+        else:
+            g = conv_bwd(b['c1'], in_op, dy1, res=g)
     # ---- first conv + PReLU -----------------------------------------------------------------------------
     g_t0 = E.add(g, g_t) if topo.long_skip else g
     if topo.first_prelu.requires_grad:

@@ -297,3 +297,31 @@ def test_wgrad_bf16_few_channel_output_padded(E, L):
         assert maxrel(gb, br.grad) < BF16_TOL, 'bias grad'
     finally:
         E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('shape,act', [((2, 64, 64, 12, 12), True), ((1, 64, 64, 37, 29), False), ((3, 32, 64, 6, 6), True)])
+def test_bn_backward_reductions_from_the_conv_epilogue(E, L, shape, act):
+    """conv_dgrad(..., bnb=...): the data-gradient conv (bf16 kernel) also emits the backward reductions of the
+    BatchNorm its output arrives at; they must equal the stand-alone reduction kernel run on the same gradient"""
+    n, cin, cout, h, w = shape
+    wt = _rand((cout, cin, 3, 3), 51, (1.0 / (cin * 9)) ** 0.5 * 1.7)
+    dy, skip, x = _rand((n, cout, h, w), 52), _rand((n, cin, h, w), 53), _rand((n, cin, h, w), 54, 2.0)
+    gamma, beta = _rand((cin,), 55) + 1.5, _rand((cin,), 56)
+    mean = x.mean(dim=(0, 2, 3))
+    invstd = torch.rsqrt(x.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    k = torch.stack([gamma * invstd, beta - mean * gamma * invstd, mean, invstd]).cuda()
+    slope = torch.tensor([0.2], device='cuda') if act else None
+    E.set_precision('bf16')
+    try:
+        ref = FakeConv(wt.cuda(), None, E.ConvGeom(cin, cout, 3, 1, 1))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        assert E.can_fuse_bn_backward(p)
+        xd = nhwc(x).cuda()
+        g, part = E.conv_dgrad(p, E.Operand.plain(nhwc(dy).cuda()), res=nhwc(skip).cuda(), bnb=(xd, k, slope))
+        fused = E.bn_backward(g, xd, k, gamma.cuda(), slope=slope, part=part)
+        plain = E.bn_backward(g, xd, k, gamma.cuda(), slope=slope)
+        for a, b in zip(fused, plain):
+            if a is not None:
+                assert maxrel(a, b) < 1e-4
+    finally:
+        E.set_precision('fp32')
