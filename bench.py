@@ -7,7 +7,8 @@ per GPU B=16 patches of 192x192 (LR 96x96).  One step = one pass of the hot path
 
     LR = lr_from_hr(HR)  ->  fake = G(LR)  ->  loss = 10 * mean((fake - HR)^2)   (identity
     extractor, config.py:158-162)  ->  backward (dgrad + wgrad of every layer)  ->  gradient
-    all-reduce over RCCL when N > 1  ->  Adam step (lr 1e-5, config.py:38,293).
+    all-reduce over RCCL when N > 1  ->  Adam step (lr 1e-5, config.py:38,293; the fused multi-tensor
+    step of optim.py).
 
 Inputs are resident in HBM before the timed region.  value = HR patches/s over all ranks.
 Also reported on the same JSON line: the roofline of the dominant kernel (the 3x3 64->64 trunk
@@ -41,7 +42,7 @@ def make_step(device, rank, world):
     mg, utils = sub('model_generator'), sub('utils')
     torch.manual_seed(0)                                      # identical replicas on every rank
     net = mg.Generator(16, 64, 256, [2], use_sn=True).to(device).train()
-    opt = torch.optim.Adam(net.parameters(), lr=1e-5, betas=(0.9, 0.999))
+    opt = sub('optim').Adam(net.parameters(), lr=1e-5, betas=(0.9, 0.999))     # fused multi-tensor step (row f1)
     g = torch.Generator().manual_seed(rank)                   # a different shard of patches per rank
     hr = (torch.rand((B, 3, HR, HR), generator=g) * 2 - 1).to(device)
     reducer = sub('distributed').GradReducer(list(net.parameters()), world) if world > 1 else None

@@ -297,6 +297,21 @@ int sisr_bicubic_bwd(const float *dy, const float *y_clamped, float *dx, int32_t
                      int32_t W, int32_t Ho, int32_t Wo, void *stream);
 
 /* ---- misc ---------------------------------------------------------------------------------- */
+/* ---- optimizer: fused multi-tensor Adam --------------------------------------------------
+ * One launch performs torch.optim.Adam's update (amsgrad=False, maximize=False; config.py:292-294, stepped at
+ * train.py:75,108) for every parameter of a network.  Table in DEVICE memory; block_start = running sum of
+ * sisr_adam_blocks(numel) over the preceding entries; total_blocks = that sum over all entries.  The caller passes
+ * lr (after any LambdaLR factor, config.py:170-180) and the bias corrections 1 - beta^t of the step being taken. */
+typedef struct SisrAdamDesc {
+    float *p, *m, *v;          /* parameter, exp_avg, exp_avg_sq (updated in place)            */
+    const float *g;            /* gradient                                                      */
+    int64_t numel;
+    int64_t block_start;
+} SisrAdamDesc;
+int64_t sisr_adam_blocks(int64_t numel);
+int sisr_adam_step(const SisrAdamDesc *table_dev, int32_t n, int64_t total_blocks, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, double bias_corr1, double bias_corr2, void *stream);
+
 /* sizeof() of the descriptor structs in declaration order (Conv, Wgrad, Weight, WeightGrad,
  * BnBwd, ConvPlan) so a binding can verify its mirror of this header; returns the count. */
 int sisr_struct_sizes(int32_t *out, int32_t cap);

@@ -9,11 +9,15 @@ The package directory name contains hyphens, so import it with
 from . import _lib  # noqa: F401
 
 
-def install():
+def install(fused_adam=False):
     """Register this package's modules under the reference's top-level module names, so the
-    reference's ``train.py`` / ``config.py`` import them unchanged."""
+    reference's ``train.py`` / ``config.py`` import them unchanged.  ``fused_adam=True`` also points
+    ``torch.optim.Adam`` (what config.py:293-294 instantiates) at the fused multi-tensor Adam of ``optim.py``."""
     import importlib
     import sys
+    if fused_adam:
+        import torch
+        torch.optim.Adam = importlib.import_module('.optim', __name__).Adam
     for name in ('model_generator', 'model_generator_progressive', 'model_discriminator',
                  'model_content_extractor', 'utils'):
         try:

@@ -76,6 +76,10 @@ class WeightGradDesc(C.Structure):
                                      'CoutPad', 'layout')])
 
 
+class AdamDesc(C.Structure):
+    _fields_ = [('p', _f), ('m', _f), ('v', _f), ('g', _f), ('numel', _i64), ('block_start', _i64)]
+
+
 class BnBwdDesc(C.Structure):
     _fields_ = ([(n, _f) for n in ('dy', 'x', 'scale', 'shift', 'mean', 'invstd', 'gamma', 'work',
                                    'qa', 'qb', 'qd', 'dgamma', 'dbeta', 'dslope')] +
@@ -104,6 +108,8 @@ _SIGS = {
     'sisr_eltwise_res_affine': [_f, _f, _f32, _f, _f, _f, _f, _i64, _i32, _f],
     'sisr_prelu_slope_grad': [_f, _f, _i64, _f, _f, _f],
     'sisr_add': [_f, _f, _f, _i64, _f],
+    'sisr_adam_blocks': [_i64],
+    'sisr_adam_step': [_f, _i32, _i64] + [C.c_double] * 7 + [_f],
     'sisr_nhwc_to_nchw': [_f, _f, _f, _f, _f32, _f, _i64, _i32, _i32, _i32, _i32, _f],
     'sisr_nchw_to_nhwc': [_f, _i64, _f, _i32, _i32, _i32, _i32, _f],
     'sisr_nchw_grad_to_nhwc4': [_f, _f, _f, _i32, _i32, _i32, _i32, _i32, _f],
@@ -151,6 +157,7 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    L.sisr_adam_blocks.restype = C.c_int64
     L.sisr_version.restype = C.c_char_p
     L.sisr_version.argtypes = []
     sizes = (_i32 * 8)()

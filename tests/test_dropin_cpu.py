@@ -38,3 +38,19 @@ def test_install_registers_reference_module_names():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_fused_adam_is_a_torch_adam_with_the_same_defaults_and_state_layout():
+    """constructor / param_groups / state_dict layout of the optimizer the reference builds (config.py:292-294);
+    the step itself needs the GPU (tests/test_gpu_optim.py)"""
+    import importlib
+    import torch
+    A = importlib.import_module('single-image-super-resolution_amd.optim').Adam
+    ps = [torch.nn.Parameter(torch.zeros(3, 3)), torch.nn.Parameter(torch.zeros(2))]
+    ours, ref = A(ps, lr=1e-5, betas=(.9, 0.999)), torch.optim.Adam(ps, lr=1e-5, betas=(.9, 0.999))
+    assert isinstance(ours, torch.optim.Adam)
+    for k in ('lr', 'betas', 'eps', 'weight_decay', 'amsgrad'):
+        assert ours.param_groups[0][k] == ref.param_groups[0][k]
+    assert ours.state_dict()['param_groups'][0]['params'] == ref.state_dict()['param_groups'][0]['params']
+    sched = torch.optim.lr_scheduler.LambdaLR(ours, lr_lambda=lambda it: 0.5 ** it)
+    assert sched.get_last_lr() == [1e-5]
