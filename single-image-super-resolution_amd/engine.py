@@ -569,11 +569,16 @@ def nchw_to_nhwc(src, src_stride, n, h, w, c):
     return y
 
 
+FC_MAX_BATCH = 16          # rows the FC kernels keep in registers (FC_B in layout_fc.hip); larger batches run in slices
+
+
 def fc_forward(x, w, b, in_slope=1.0, sigmoid=False):
     bsz, k = x.shape
     y = torch.empty((bsz, w.shape[0]), dtype=torch.float32, device=x.device)
-    L.check(L.lib().sisr_fc_forward(x.data_ptr(), in_slope, w.data_ptr(), _ptr(b), y.data_ptr(), bsz, k,
-                                    w.shape[0], int(sigmoid), _stream()), 'sisr_fc_forward')
+    for b0 in range(0, bsz, FC_MAX_BATCH):
+        nb = min(FC_MAX_BATCH, bsz - b0)
+        L.check(L.lib().sisr_fc_forward(x[b0:b0 + nb].data_ptr(), in_slope, w.data_ptr(), _ptr(b), y[b0:b0 + nb].data_ptr(),
+                                        nb, k, w.shape[0], int(sigmoid), _stream()), 'sisr_fc_forward')
     return y
 
 
@@ -582,17 +587,21 @@ def fc_backward(dy, x, w, in_slope=1.0, need_dx=True):
     lib = L.lib()
     bsz, k = x.shape
     nout = w.shape[0]
-    dw = torch.empty_like(w)
-    db = torch.empty((nout,), dtype=torch.float32, device=x.device)
-    L.check(lib.sisr_fc_wgrad(dy.data_ptr(), x.data_ptr(), in_slope, dw.data_ptr(), db.data_ptr(), bsz, k, nout,
-                              _stream()), 'sisr_fc_wgrad')
-    dx = None
-    if need_dx:
-        splits = lib.sisr_fc_dgrad_splits(k, nout)
-        work = torch.empty((splits, bsz, k), dtype=torch.float32, device=x.device)
-        dx = torch.empty((bsz, k), dtype=torch.float32, device=x.device)
-        L.check(lib.sisr_fc_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), work.data_ptr(), bsz, k, nout,
-                                  _stream()), 'sisr_fc_dgrad')
+    dw = db = None
+    dx = torch.empty((bsz, k), dtype=torch.float32, device=x.device) if need_dx else None
+    for b0 in range(0, bsz, FC_MAX_BATCH):
+        nb = min(FC_MAX_BATCH, bsz - b0)
+        dyc, xc = dy[b0:b0 + nb], x[b0:b0 + nb]
+        dwc = torch.empty_like(w)
+        dbc = torch.empty((nout,), dtype=torch.float32, device=x.device)
+        L.check(lib.sisr_fc_wgrad(dyc.data_ptr(), xc.data_ptr(), in_slope, dwc.data_ptr(), dbc.data_ptr(), nb, k, nout,
+                                  _stream()), 'sisr_fc_wgrad')
+        dw, db = (dwc, dbc) if dw is None else (add(dw, dwc), add(db, dbc))     # batch slices sum into the gradient
+        if need_dx:
+            splits = lib.sisr_fc_dgrad_splits(k, nout)
+            work = torch.empty((splits, nb, k), dtype=torch.float32, device=x.device)
+            L.check(lib.sisr_fc_dgrad(dyc.data_ptr(), w.data_ptr(), dx[b0:b0 + nb].data_ptr(), work.data_ptr(), nb, k, nout,
+                                      _stream()), 'sisr_fc_dgrad')
     return dx, dw, db
 
 

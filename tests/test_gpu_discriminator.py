@@ -66,3 +66,26 @@ def test_discriminator_srgan_lists_32px():
             ref[k[11:]] = torch.from_numpy(z[k])
             got[k[11:]] = flat[:: max(1, flat.numel() // 4096)][:4096]
     assert grads_close(got, ref, TOL) == []
+
+
+def test_discriminator_batch_larger_than_the_fc_register_tile():
+    """batch 20 > 16: the FC kernels run in batch slices whose weight gradients are summed; checked against the
+    oracle on the same seeded input (1e-3)"""
+    from helpers import oracle_fwd_bwd
+    z, cfg, state, grads, after = load_case('dis_16px_w16')
+    g = torch.Generator().manual_seed(5)
+    shape = (20,) + tuple(z['x'].shape[1:])
+    x = torch.rand(shape, generator=g) * 2 - 1
+    r = torch.rand((20, 1), generator=g) * 2 - 1
+    out_ref, gx_ref, grads_ref, _ = oracle_fwd_bwd(cfg, state, x, r)
+    md = pkg('model_discriminator')
+    net = md.Discriminator(tuple(cfg['input_shape']), cfg['list_n_features'], cfg['list_stride'])
+    net.load_state_dict(state, strict=True)
+    net = net.cuda().train()
+    xd = x.cuda().requires_grad_(True)
+    out = net(xd)
+    assert rel_err(out.detach().cpu(), out_ref) < TOL
+    (out * r.cuda()).sum().backward()
+    assert rel_err(xd.grad.cpu(), gx_ref) < TOL
+    got = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+    assert grads_close(got, grads_ref, TOL) == []
