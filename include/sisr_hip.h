@@ -151,6 +151,7 @@ typedef struct SisrWeightDesc {
     float *u, *v;             /* spectral-norm buffers (updated in place when training) or NULL */
     float *u_used, *v_used;   /* copies of the u/v that define sigma (for backward) or NULL   */
     float *sigma;             /* [1] out (1.0 when u == NULL)                                 */
+    float *sn_work;           /* power-iteration scratch, >= ceil(Cout/64)*Cin*KH*KW + Cout floats (u != NULL) */
     float *wpk_fwd;           /* packed W/sigma for the forward conv, or NULL                 */
     float *wpk_dgrad;         /* packed flipped/transposed W/sigma for the data gradient, or NULL */
     int32_t Cout, Cin, KH, KW;
@@ -172,7 +173,9 @@ typedef struct SisrWeightDesc {
     int32_t bf_f_CK, bf_d_CK;   /* in-channel chunk of the bf16 images: 32 (generic) or 64 (persistent kernel) */
 } SisrWeightDesc;
 
-int sisr_weights_prepare(const SisrWeightDesc *table_dev, int32_t n, void *stream);
+/* max_rows / max_cols: largest Cout and Cin*KH*KW over the table (the launch grids are sized from them) */
+int sisr_weights_prepare(const SisrWeightDesc *table_dev, int32_t n, int32_t max_rows, int32_t max_cols,
+                         void *stream);
 
 /* Weight-gradient epilogue: packed dW (sum of slabs) -> OIHW gradient of w_orig, through the
  * spectral-norm quotient: dW_orig = (G - <G, W> u v^T) / sigma  (autograd of W = W_orig/sigma with
@@ -189,8 +192,10 @@ typedef struct SisrWeightGradDesc {
                                  [chunk32][tap][ci][co]                                          */
 } SisrWeightGradDesc;
 
-/* dot_work: >= 16*n floats of scratch */
-int sisr_weights_grad(const SisrWeightGradDesc *table_dev, int32_t n, float *dot_work, void *stream);
+/* parts = sisr_weights_grad_parts(largest Cout*Cin*KH*KW of the table): workgroups per weight;
+ * dot_work: >= parts*n floats of scratch */
+int sisr_weights_grad_parts(int64_t max_elems);
+int sisr_weights_grad(const SisrWeightGradDesc *table_dev, int32_t n, float *dot_work, int32_t parts, void *stream);
 
 /* ---- BatchNorm2d (training) pieces that are not fused into the convolutions ------------------
  * finalize: merge the per-tile (mean, M2) partials (Chan et al.), produce the fused apply

@@ -58,7 +58,7 @@ class WgradDesc(C.Structure):
 
 
 class WeightDesc(C.Structure):
-    _fields_ = ([(n, _f) for n in ('w_orig', 'u', 'v', 'u_used', 'v_used', 'sigma', 'wpk_fwd', 'wpk_dgrad')] +
+    _fields_ = ([(n, _f) for n in ('w_orig', 'u', 'v', 'u_used', 'v_used', 'sigma', 'sn_work', 'wpk_fwd', 'wpk_dgrad')] +
                 [(n, _i32) for n in ('Cout', 'Cin', 'KH', 'KW', 'training', 'shuffle2',
                                      'f_CK', 'f_PS', 'f_KROWP', 'f_n_chunk', 'f_CoutPad',
                                      'd_CK', 'd_PS', 'd_KROWP', 'd_n_chunk', 'd_CoutPad')] +
@@ -98,8 +98,9 @@ _SIGS = {
     'sisr_conv2d_wgrad_bf16': [C.POINTER(WgradDesc), _f],
     'sisr_tr16_selftest': [_f, _f],
     'sisr_slab_reduce_f32': [_f, _f, _i32, _i64, _f],
-    'sisr_weights_prepare': [_f, _i32, _f],
-    'sisr_weights_grad': [_f, _i32, _f, _f],
+    'sisr_weights_prepare': [_f, _i32, _i32, _i32, _f],
+    'sisr_weights_grad_parts': [_i64],
+    'sisr_weights_grad': [_f, _i32, _f, _i32, _f],
     'sisr_bn_finalize': [_f, _f, _i32, _i32, _f, _f, _f, _f, _f32, _f32, _f, _f, _f, _f, _f],
     'sisr_bn_eval_consts': [_f, _f, _f, _f, _f32, _i32, _f, _f, _f],
     'sisr_bn_bwd_plan': [C.POINTER(BnBwdDesc)],

@@ -13,63 +13,111 @@
 
 #define SN_EPS 1e-12f
 
-// phase 1: one workgroup per weight -> sigma (+ in-place u/v update, + copies for backward)
-__global__ void __launch_bounds__(SISR_BLOCK) weights_sigma_kernel(const SisrWeightDesc* table) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];
+// Power iteration in four short multi-tensor launches (grid = (weights, jobs); surplus workgroups exit), so
+// the 512x4608 matrices of the discriminator are spread over the chip instead of one workgroup per matrix:
+//   A  t_part[rb][j] = sum_{i in row block rb} W[i][j] u[i]        (workgroup = 64 rows x 1024 columns)
+//   B  t = sum_rb t_part ; v = t / max(|t|, eps)                   (one workgroup per weight)
+//   C  s[i] = W[i,:] . v                                           (wave per row, 4 rows per workgroup)
+//   D  u = s / max(|s|, eps) ; sigma = u . s                       (one workgroup per weight)
+// Evaluation mode skips A/B (v is kept) and D keeps the stored u.  sn_work per weight: [RB][cols] + [rows] floats.
+#define SN_RB 64
+#define SN_CB 1024
+__device__ __forceinline__ int sn_rblocks(int rows) { return (rows + SN_RB - 1) / SN_RB; }
+
+__global__ void __launch_bounds__(SISR_BLOCK) sn_wt_u_kernel(const SisrWeightDesc* table) {
+    __shared__ float us[SN_RB];
+    const SisrWeightDesc w = table[blockIdx.x];
+    if (w.u == nullptr || !w.training) return;
+    const int rows = w.Cout, cols = w.Cin * w.KH * w.KW;
+    const int ncb = (cols + SN_CB - 1) / SN_CB, job = blockIdx.y;
+    if (job >= sn_rblocks(rows) * ncb) return;
+    const int rb = job / ncb, cb = job - rb * ncb;
+    const int r0 = rb * SN_RB, nr = min(SN_RB, rows - r0);
+    if (threadIdx.x < nr) us[threadIdx.x] = w.u[r0 + threadIdx.x];
+    __syncthreads();
+    float acc[SN_CB / SISR_BLOCK];
+#pragma unroll
+    for (int k = 0; k < SN_CB / SISR_BLOCK; ++k) acc[k] = 0.f;
+    const int j0 = cb * SN_CB + threadIdx.x;
+    const float* wp = w.w_orig + (int64_t)r0 * cols;
+    for (int i = 0; i < nr; ++i, wp += cols) {
+        const float ui = us[i];
+#pragma unroll
+        for (int k = 0; k < SN_CB / SISR_BLOCK; ++k) {
+            const int j = j0 + k * SISR_BLOCK;
+            if (j < cols) acc[k] += wp[j] * ui;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SN_CB / SISR_BLOCK; ++k) {
+        const int j = j0 + k * SISR_BLOCK;
+        if (j < cols) w.sn_work[(int64_t)rb * cols + j] = acc[k];
+    }
+}
+
+__global__ void __launch_bounds__(SISR_BLOCK) sn_v_finish_kernel(const SisrWeightDesc* table) {
     __shared__ float scratch[8];
     const SisrWeightDesc w = table[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (w.u == nullptr) return;
+    const int rows = w.Cout, cols = w.Cin * w.KH * w.KW, tid = threadIdx.x;
+    if (!w.training) {
+        if (w.v_used) for (int j = tid; j < cols; j += SISR_BLOCK) w.v_used[j] = w.v[j];
+        return;
+    }
+    const int nrb = sn_rblocks(rows);
+    float part = 0.f;
+    for (int j = tid; j < cols; j += SISR_BLOCK) {
+        float t = 0.f;
+        for (int rb = 0; rb < nrb; ++rb) t += w.sn_work[(int64_t)rb * cols + j];
+        w.sn_work[j] = t;                               // row block 0 now holds the full sum
+        part += t * t;
+    }
+    const float iv = 1.f / fmaxf(sqrtf(block_sum(part, scratch)), SN_EPS);
+    for (int j = tid; j < cols; j += SISR_BLOCK) {
+        const float v = w.sn_work[j] * iv;
+        w.v[j] = v;
+        if (w.v_used) w.v_used[j] = v;
+    }
+}
+
+__global__ void __launch_bounds__(SISR_BLOCK) sn_w_v_kernel(const SisrWeightDesc* table) {
+    const SisrWeightDesc w = table[blockIdx.x];
+    if (w.u == nullptr) return;
     const int rows = w.Cout, cols = w.Cin * w.KH * w.KW;
+    const int lane = threadIdx.x & 63, i = blockIdx.y * (SISR_BLOCK / 64) + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    const float* wr = w.w_orig + (int64_t)i * cols;
+    float a = 0.f;
+    for (int j = lane; j < cols; j += 64) a += wr[j] * w.v[j];
+    a = wave_sum(a);
+    if (lane == 0) w.sn_work[(int64_t)sn_rblocks(rows) * cols + i] = a;
+}
+
+__global__ void __launch_bounds__(SISR_BLOCK) sn_u_finish_kernel(const SisrWeightDesc* table) {
+    __shared__ float scratch[8];
+    const SisrWeightDesc w = table[blockIdx.x];
+    const int tid = threadIdx.x;
     if (w.u == nullptr) {
         if (tid == 0 && w.sigma) w.sigma[0] = 1.f;
         return;
     }
-    float* us = sh;            // [rows]
-    float* vs = sh + rows;     // [cols]
-    float* ss = vs + cols;     // [rows]
-    for (int i = tid; i < rows; i += SISR_BLOCK) us[i] = w.u[i];
-    for (int j = tid; j < cols; j += SISR_BLOCK) vs[j] = w.v[j];
-    __syncthreads();
-    if (w.training) {
-        // t = W^T u (thread per column: coalesced along the row-major weight matrix)
-        float part = 0.f;
-        for (int j = tid; j < cols; j += SISR_BLOCK) {
-            float a = 0.f;
-            for (int i = 0; i < rows; ++i) a += w.w_orig[(int64_t)i * cols + j] * us[i];
-            vs[j] = a;
-            part += a * a;
-        }
-        const float nv = sqrtf(block_sum(part, scratch));
-        const float iv = 1.f / fmaxf(nv, SN_EPS);
-        for (int j = tid; j < cols; j += SISR_BLOCK) vs[j] *= iv;
-        __syncthreads();
-    }
-    // s = W v (wave per row)
-    for (int i = wave; i < rows; i += SISR_BLOCK / 64) {
-        float a = 0.f;
-        for (int j = lane; j < cols; j += 64) a += w.w_orig[(int64_t)i * cols + j] * vs[j];
-        a = wave_sum(a);
-        if (lane == 0) ss[i] = a;
-    }
-    __syncthreads();
+    const int rows = w.Cout, cols = w.Cin * w.KH * w.KW;
+    const float* s = w.sn_work + (int64_t)sn_rblocks(rows) * cols;
+    float iu = 0.f;
     if (w.training) {
         float part = 0.f;
-        for (int i = tid; i < rows; i += SISR_BLOCK) part += ss[i] * ss[i];
-        const float nu = sqrtf(block_sum(part, scratch));
-        const float iu = 1.f / fmaxf(nu, SN_EPS);
-        for (int i = tid; i < rows; i += SISR_BLOCK) us[i] = ss[i] * iu;
-        __syncthreads();
+        for (int i = tid; i < rows; i += SISR_BLOCK) part += s[i] * s[i];
+        iu = 1.f / fmaxf(sqrtf(block_sum(part, scratch)), SN_EPS);
     }
     float part = 0.f;
-    for (int i = tid; i < rows; i += SISR_BLOCK) part += us[i] * ss[i];
+    for (int i = tid; i < rows; i += SISR_BLOCK) {
+        const float u = w.training ? s[i] * iu : w.u[i];
+        part += u * s[i];
+        if (w.training) w.u[i] = u;
+        if (w.u_used) w.u_used[i] = u;
+    }
     const float sigma = block_sum(part, scratch);
     if (tid == 0 && w.sigma) w.sigma[0] = sigma;
-    if (w.training) {
-        for (int i = tid; i < rows; i += SISR_BLOCK) w.u[i] = us[i];
-        for (int j = tid; j < cols; j += SISR_BLOCK) w.v[j] = vs[j];
-    }
-    if (w.u_used) for (int i = tid; i < rows; i += SISR_BLOCK) w.u_used[i] = us[i];
-    if (w.v_used) for (int j = tid; j < cols; j += SISR_BLOCK) w.v_used[j] = vs[j];
 }
 
 // packed channel index -> original output channel (PixelShuffle(2) consumers use (i,j)-major order)
@@ -193,7 +241,6 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
 // weight-gradient epilogue, two launches over grid (n_weights, WG_PARTS):
 //   1. partial <G, W_orig> per (weight, part)  -> dot_part[w][part]   (deterministic order)
 //   2. every part sums the WG_PARTS partials of its weight and writes its share of the OIHW gradient
-#define WG_PARTS 16
 __device__ __forceinline__ int64_t wg_packed_index(const SisrWeightGradDesc& w, int64_t e) {
     const int Cq = w.Cout >> 2;
     int64_t tq = e;
@@ -213,6 +260,7 @@ __device__ __forceinline__ int64_t wg_packed_index(const SisrWeightGradDesc& w, 
 
 __global__ void __launch_bounds__(SISR_BLOCK) weights_grad_dot_kernel(const SisrWeightGradDesc* table,
                                                                      float* dot_part) {
+    const int WG_PARTS = gridDim.y;
     __shared__ float scratch[8];
     const SisrWeightGradDesc w = table[blockIdx.x];
     float part = 0.f;
@@ -227,6 +275,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_grad_dot_kernel(const Sisr
 
 __global__ void __launch_bounds__(SISR_BLOCK) weights_grad_kernel(const SisrWeightGradDesc* table,
                                                                  const float* dot_part) {
+    const int WG_PARTS = gridDim.y;
     const SisrWeightGradDesc w = table[blockIdx.x];
     const int tid = threadIdx.x;
     const int cols = w.Cin * w.KH * w.KW;
@@ -253,24 +302,39 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_grad_kernel(const SisrWeig
     }
 }
 
-extern "C" int sisr_weights_prepare(const SisrWeightDesc* table_dev, int32_t n, void* stream) {
-    if (!table_dev || n <= 0) return SISR_E_BADARG;
+static int parts_for(int64_t elems) {           // workgroups per weight for the element-wise multi-tensor kernels
+    const int64_t want = (elems + 4095) / 4096;   // ~16 elements per thread
+    return (int)std::max<int64_t>(16, std::min<int64_t>(want, 1024));
+}
+
+extern "C" int sisr_weights_prepare(const SisrWeightDesc* table_dev, int32_t n, int32_t max_rows, int32_t max_cols,
+                                    void* stream) {
+    if (!table_dev || n <= 0 || max_rows <= 0 || max_cols <= 0) return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // LDS for the largest supported matrix: rows <= 1024, cols <= 9216
-    const int lds = (2 * 1024 + 9216) * 4;
-    hipLaunchKernelGGL(weights_sigma_kernel, dim3(n), dim3(SISR_BLOCK), lds, st, table_dev);
+    const int jobs_a = ((max_rows + SN_RB - 1) / SN_RB) * ((max_cols + SN_CB - 1) / SN_CB);
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(n, jobs_a), dim3(SISR_BLOCK), 0, st, table_dev);
     SISR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(weights_pack_kernel, dim3(n, 16), dim3(SISR_BLOCK), 0, st, table_dev);
+    hipLaunchKernelGGL(sn_v_finish_kernel, dim3(n), dim3(SISR_BLOCK), 0, st, table_dev);
+    SISR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(n, (max_rows + 3) / 4), dim3(SISR_BLOCK), 0, st, table_dev);
+    SISR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sn_u_finish_kernel, dim3(n), dim3(SISR_BLOCK), 0, st, table_dev);
+    SISR_CHECK_LAUNCH();
+    // packed images are a little larger than the matrix (padding slots): parts from 2x its size
+    hipLaunchKernelGGL(weights_pack_kernel, dim3(n, parts_for(2ll * max_rows * max_cols)), dim3(SISR_BLOCK), 0, st, table_dev);
     SISR_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int sisr_weights_grad(const SisrWeightGradDesc* table_dev, int32_t n, float* dot_work, void* stream) {
-    if (!table_dev || n <= 0 || !dot_work) return SISR_E_BADARG;
+extern "C" int sisr_weights_grad_parts(int64_t max_elems) { return parts_for(max_elems); }
+
+extern "C" int sisr_weights_grad(const SisrWeightGradDesc* table_dev, int32_t n, float* dot_work, int32_t parts,
+                                 void* stream) {
+    if (!table_dev || n <= 0 || !dot_work || parts <= 0) return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(weights_grad_dot_kernel, dim3(n, WG_PARTS), dim3(SISR_BLOCK), 0, st, table_dev, dot_work);
+    hipLaunchKernelGGL(weights_grad_dot_kernel, dim3(n, parts), dim3(SISR_BLOCK), 0, st, table_dev, dot_work);
     SISR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(weights_grad_kernel, dim3(n, WG_PARTS), dim3(SISR_BLOCK), 0, st, table_dev, dot_work);
+    hipLaunchKernelGGL(weights_grad_kernel, dim3(n, parts), dim3(SISR_BLOCK), 0, st, table_dev, dot_work);
     SISR_CHECK_LAUNCH();
     return 0;
 }

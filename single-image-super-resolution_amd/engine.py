@@ -204,13 +204,17 @@ def prepare_weights(items, training, need_dgrad=True):
             off_d = total
             total += _align4((d.plan.wpk_elems + 1) // 2 if kinds[1] else d.plan.wpk_elems)
         off_s = small
-        small += 4 + (_align4(ref.geom.cout) + _align4(ref.geom.cin * ref.geom.k * ref.geom.k) if ref.u is not None else 0)
-        metas.append((off_f, off_d, off_s))
+        rows_, cols_ = ref.geom.cout, ref.geom.cin * ref.geom.k * ref.geom.k
+        small += 4 + (_align4(rows_) + _align4(cols_) if ref.u is not None else 0)
+        off_w = small                              # power-iteration scratch: [ceil(rows/64)][cols] + [rows]
+        small += _align4((rows_ + 63) // 64 * cols_ + rows_) if ref.u is not None else 0
+        metas.append((off_f, off_d, off_s, off_w))
     big = torch.empty(total, dtype=torch.float32, device=dev)
     sm = torch.empty(small, dtype=torch.float32, device=dev)
     table = (L.WeightDesc * len(items))()
     out = []
-    for i, ((ref, n, h, w), (off_f, off_d, off_s)) in enumerate(zip(items, metas)):
+    max_rows = max_cols = 1
+    for i, ((ref, n, h, w), (off_f, off_d, off_s, off_w)) in enumerate(zip(items, metas)):
         f, d, g, kinds = ref.geom.plans(n, h, w)
         gm = ref.geom
         p = Prepared()
@@ -250,17 +254,18 @@ def prepare_weights(items, training, need_dgrad=True):
             t.d_CK, t.d_PS, t.d_KROWP, t.d_n_chunk, t.d_CoutPad = (d.plan.CK, d.plan.PS, d.plan.KROWP,
                                                                      d.plan.n_chunk, d.plan.CoutPad)
         p.u_used = p.v_used = None
+        max_rows, max_cols = max(max_rows, gm.cout), max(max_cols, gm.cin * gm.k * gm.k)
         if ref.u is not None:
             rows, cols = gm.cout, gm.cin * gm.k * gm.k
-            if rows > 1024 or cols > 9216:
-                raise RuntimeError('spectral-norm matrix %dx%d exceeds the kernel limit' % (rows, cols))
+            t.sn_work = sm[off_w:].data_ptr()
             p.u_used = sm[off_s + 4:off_s + 4 + rows]
             p.v_used = sm[off_s + 4 + _align4(rows):off_s + 4 + _align4(rows) + cols]
             t.u, t.v = ref.u.data_ptr(), ref.v.data_ptr()
             t.u_used, t.v_used = p.u_used.data_ptr(), p.v_used.data_ptr()
         out.append(p)
     tab_dev = _table_to_device(table, dev)
-    L.check(lib.sisr_weights_prepare(tab_dev.data_ptr(), len(items), _stream()), 'sisr_weights_prepare')
+    L.check(lib.sisr_weights_prepare(tab_dev.data_ptr(), len(items), max_rows, max_cols, _stream()),
+            'sisr_weights_prepare')
     return out, (big, sm, tab_dev)
 
 
@@ -453,8 +458,9 @@ class WeightGradBatch:
             t.layout = 1 if p.kinds[2] else 0
             res[id(p.ref)] = (gw, gb)
         tab = _table_to_device(table, dev)
-        work = torch.empty((16 * len(self.items),), dtype=torch.float32, device=dev)
-        L.check(lib.sisr_weights_grad(tab.data_ptr(), len(self.items), work.data_ptr(), _stream()),
+        parts = lib.sisr_weights_grad_parts(max(p.ref.weight.numel() for p, _, _, _ in self.items))
+        work = torch.empty((parts * len(self.items),), dtype=torch.float32, device=dev)
+        L.check(lib.sisr_weights_grad(tab.data_ptr(), len(self.items), work.data_ptr(), parts, _stream()),
                 'sisr_weights_grad')
         self._keep = (tab, work)
         return res
