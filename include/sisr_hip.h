@@ -171,6 +171,8 @@ typedef struct SisrWeightDesc {
     void *wbf_fwd, *wbf_dgrad;
     int32_t bf_f_CoutPad, bf_d_CoutPad;
     int32_t bf_f_CK, bf_d_CK;   /* in-channel chunk of the bf16 images: 32 (generic) or 64 (persistent kernel) */
+    void *wbf_dcls[4];          /* bf16 images of the stride-2 parity classes (chunks of 32), or NULL: then wpk_dcls */
+    int32_t bf_c_CoutPad[4];
 } SisrWeightDesc;
 
 /* max_rows / max_cols: largest Cout and Cin*KH*KW over the table (the launch grids are sized from them) */

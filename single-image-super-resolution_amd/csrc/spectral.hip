@@ -214,7 +214,26 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
             dst[e] = (__bf16)val;
         }
     }
-    // stride-2 data gradient: one packed image per output parity class
+    // stride-2 data gradient: one packed image per output parity class (bf16 image for the bf16 kernels)
+    for (int cls = 0; cls < 4; ++cls) {
+        __bf16* dst = reinterpret_cast<__bf16*>(w.wbf_dcls[cls]);
+        if (dst == nullptr) continue;
+        const int KHc = w.c_KH[cls], KWc = w.c_KW[cls], WSG = KHc * KWc * 32, CoutPad = w.bf_c_CoutPad[cls];
+        const int64_t total = (int64_t)(w.Cout / 32) * CoutPad * WSG;
+        for (int64_t e = start; e < total; e += stride) {
+            int64_t tq = e;
+            const int kidx = (int)(tq % WSG); tq /= WSG;
+            const int op = (int)(tq % CoutPad);
+            const int chunk = (int)(tq / CoutPad);
+            const int tap = kidx >> 5, il = kidx & 31;
+            const int rp = tap / KWc, sp = tap - rp * KWc, ip = chunk * 32 + il;
+            const int r = w.c_R0y[cls] - 2 * rp, sx = w.c_R0x[cls] - 2 * sp;
+            float val = 0.f;
+            if (op < w.Cin && r >= 0 && r < w.KH && sx >= 0 && sx < w.KW)
+                val = w.w_orig[(((int64_t)ip * w.Cin + op) * w.KH + r) * w.KW + sx] * inv;
+            dst[e] = (__bf16)val;
+        }
+    }
     for (int cls = 0; cls < 4; ++cls) {
         float* dst = w.wpk_dcls[cls];
         if (dst == nullptr) continue;

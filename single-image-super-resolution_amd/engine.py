@@ -105,8 +105,10 @@ class ConvGeom:
         d.KH, d.KW, d.stride, d.pad_y, d.pad_x = khc, kwc, 1, pady, padx
         d.y_sy = d.y_sx = 2
         d.y_oy, d.y_ox, d.y_H, d.y_W = py, px, h, w
-        L.check(lib.sisr_conv2d_plan(C.byref(d)), 'sisr_conv2d_plan(dgrad stride-2 class)')
-        return (d, r0y, r0x)
+        bf = PRECISION == 'bf16' and self.cout % 32 == 0 and lib.sisr_conv2d_plan_bf16(C.byref(d)) == 0
+        if not bf:
+            L.check(lib.sisr_conv2d_plan(C.byref(d)), 'sisr_conv2d_plan(dgrad stride-2 class)')
+        return (d, r0y, r0x, bool(bf))
 
     def plans(self, n, h, w, max_pixel_blocks=512):
         """-> (fwd desc, dgrad desc | [4 class descs] | None, wgrad desc, kinds) where kinds =
@@ -199,7 +201,7 @@ def prepare_weights(items, training, need_dgrad=True):
             for cls in d:
                 off_d.append(None if cls is None else total)
                 if cls is not None:
-                    total += _align4(cls[0].plan.wpk_elems)
+                    total += _align4((cls[0].plan.wpk_elems + 1) // 2 if cls[3] else cls[0].plan.wpk_elems)
         elif need_dgrad and d is not None:
             off_d = total
             total += _align4((d.plan.wpk_elems + 1) // 2 if kinds[1] else d.plan.wpk_elems)
@@ -221,7 +223,9 @@ def prepare_weights(items, training, need_dgrad=True):
         p.ref, p.plans, p.kinds = ref, (f, d, g), kinds
         p.wpk_fwd = big[off_f:off_f + ((f.plan.wpk_elems + 1) // 2 if kinds[0] else f.plan.wpk_elems)]
         if isinstance(off_d, list):
-            p.wpk_dgrad = [None if o is None else big[o:o + cls[0].plan.wpk_elems] for o, cls in zip(off_d, d)]
+            p.wpk_dgrad = [None if o is None else
+                           big[o:o + ((cls[0].plan.wpk_elems + 1) // 2 if cls[3] else cls[0].plan.wpk_elems)]
+                           for o, cls in zip(off_d, d)]
         else:
             p.wpk_dgrad = (big[off_d:off_d + ((d.plan.wpk_elems + 1) // 2 if kinds[1] else d.plan.wpk_elems)]
                            if off_d is not None else None)
@@ -245,9 +249,12 @@ def prepare_weights(items, training, need_dgrad=True):
             for ci, (cls, buf) in enumerate(zip(d, p.wpk_dgrad)):
                 if cls is None:
                     continue
-                cd, r0y, r0x = cls
-                t.wpk_dcls[ci] = buf.data_ptr()
+                cd, r0y, r0x, cbf = cls
                 t.c_KH[ci], t.c_KW[ci], t.c_R0y[ci], t.c_R0x[ci] = cd.KH, cd.KW, r0y, r0x
+                if cbf:
+                    t.wbf_dcls[ci], t.bf_c_CoutPad[ci] = buf.data_ptr(), cd.plan.CoutPad
+                    continue
+                t.wpk_dcls[ci] = buf.data_ptr()
                 t.c_CK[ci], t.c_PS[ci], t.c_KROWP[ci] = cd.plan.CK, cd.plan.PS, cd.plan.KROWP
                 t.c_n_chunk[ci], t.c_CoutPad[ci] = cd.plan.n_chunk, cd.plan.CoutPad
         elif off_d is not None and not kinds[1]:
@@ -362,7 +369,10 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
             assert tuple(dy_op.dims) == (d.N, d.H, d.W, d.Cin), (dy_op.dims, (d.N, d.H, d.W, d.Cin))
             dy_op.fill(d)
             d.wpk, d.bias, d.res, d.y = buf.data_ptr(), None, _ptr(res), out.data_ptr()
-            L.check(lib.sisr_conv2d_f32(C.byref(d), _stream()), 'sisr_conv2d_f32(dgrad s2)')
+            if cls[3]:
+                L.check(lib.sisr_conv2d_bf16(C.byref(d), _stream()), 'sisr_conv2d_bf16(dgrad s2)')
+            else:
+                L.check(lib.sisr_conv2d_f32(C.byref(d), _stream()), 'sisr_conv2d_f32(dgrad s2)')
         return out
     d = _copy_struct(prep.plans[1])
     assert tuple(dy_op.dims) == (d.N, d.H, d.W, d.Cin), (dy_op.dims, (d.N, d.H, d.W, d.Cin))
