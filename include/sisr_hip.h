@@ -194,9 +194,8 @@ typedef struct SisrWeightGradDesc {
                                  [chunk32][tap][ci][co]                                          */
 } SisrWeightGradDesc;
 
-/* parts = sisr_weights_grad_parts(largest Cout*Cin*KH*KW of the table): workgroups per weight;
- * dot_work: >= parts*n floats of scratch */
-int sisr_weights_grad_parts(int64_t max_elems);
+/* parts = the largest tile count of the table, tiles of a weight = ceil(Cout/32) * ceil(Cin/C) with C = 32 for
+ * layout 1 (bf16 slabs) and CK otherwise; dot_work: >= parts*n floats of scratch */
 int sisr_weights_grad(const SisrWeightGradDesc *table_dev, int32_t n, float *dot_work, int32_t parts, void *stream);
 
 /* ---- BatchNorm2d (training) pieces that are not fused into the convolutions ------------------

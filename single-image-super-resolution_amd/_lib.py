@@ -99,7 +99,6 @@ _SIGS = {
     'sisr_tr16_selftest': [_f, _f],
     'sisr_slab_reduce_f32': [_f, _f, _i32, _i64, _f],
     'sisr_weights_prepare': [_f, _i32, _i32, _i32, _f],
-    'sisr_weights_grad_parts': [_i64],
     'sisr_weights_grad': [_f, _i32, _f, _i32, _f],
     'sisr_bn_finalize': [_f, _f, _i32, _i32, _f, _f, _f, _f, _f32, _f32, _f, _f, _f, _f, _f],
     'sisr_bn_eval_consts': [_f, _f, _f, _f, _f32, _i32, _f, _f, _f],

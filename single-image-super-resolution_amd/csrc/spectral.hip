@@ -257,68 +257,89 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
     }
 }
 
-// weight-gradient epilogue, two launches over grid (n_weights, WG_PARTS):
-//   1. partial <G, W_orig> per (weight, part)  -> dot_part[w][part]   (deterministic order)
-//   2. every part sums the WG_PARTS partials of its weight and writes its share of the OIHW gradient
-__device__ __forceinline__ int64_t wg_packed_index(const SisrWeightGradDesc& w, int64_t e) {
-    const int Cq = w.Cout >> 2;
-    int64_t tq = e;
-    const int s = (int)(tq % w.KW); tq /= w.KW;
-    const int r = (int)(tq % w.KH); tq /= w.KH;
-    const int ci = (int)(tq % w.Cin);
-    const int co = (int)(tq / w.Cin);
-    const int cp = w.shuffle2 ? ((co & 3) * Cq + (co >> 2)) : co;
-    if (w.layout == 1) {     // wgrad_bf16.hip slabs: [chunk32][tap][ci 32][CoutPad]
-        const int chunk = ci >> 5, cl = ci & 31;
-        return ((int64_t)(chunk * w.KH * w.KW + r * w.KW + s) * 32 + cl) * w.CoutPad + cp;
-    }
-    const int chunk = ci / w.CK, cl = ci - chunk * w.CK;
-    const int krow = s * w.PS + cl;
-    return ((int64_t)(chunk * w.KH + r) * w.KROWP + krow) * w.CoutPad + cp;
+// weight-gradient epilogue: the reduced packed gradient is a [K rows][CoutPad] matrix (K = chunk, tap, channel
+// in the conv kernels' order), the parameter gradient is OIHW -- a transpose with a row permutation.  A workgroup
+// takes one tile (32 packed couts x one channel chunk x all taps) through LDS: coalesced 128-byte reads along the
+// couts, contiguous writes along (ci, r, s).  Two launches over grid (weights, max tiles per weight):
+//   1. partial <G, W_orig> per tile  -> dot_part[w][tile]   (deterministic order)
+//   2. every tile sums the partials of its weight and writes its share of the OIHW gradient
+#define WGT_ROWS 324                                     // LDS rows per pass (taps x channels of the chunk)
+__device__ __forceinline__ int wgt_tiles(const SisrWeightGradDesc& w) {
+    const int ck = w.layout == 1 ? 32 : w.CK;
+    return ((w.Cout + 31) / 32) * ((w.Cin + ck - 1) / ck);
 }
 
-__global__ void __launch_bounds__(SISR_BLOCK) weights_grad_dot_kernel(const SisrWeightGradDesc* table,
-                                                                     float* dot_part) {
-    const int WG_PARTS = gridDim.y;
+// mode 0: returns this thread's share of <G, W_orig> over the tile; mode 1: writes the gradient
+template <int MODE>
+__device__ __forceinline__ float wgt_tile(const SisrWeightGradDesc& w, int tile, float* lds, float gw, float inv) {
+    const int tid = threadIdx.x;
+    const int n_cot = (w.Cout + 31) / 32;
+    const int cot = tile % n_cot, chunk = tile / n_cot;
+    const int ck = w.layout == 1 ? 32 : w.CK;
+    const int ci0 = chunk * ck, nci = min(ck, w.Cin - ci0);
+    const int taps = w.KH * w.KW, cols = w.Cin * taps, Cq = w.Cout >> 2;
+    const int tgroup = max(1, min(taps, WGT_ROWS / nci));           // taps per LDS pass
+    float part = 0.f;
+    for (int t0 = 0; t0 < taps; t0 += tgroup) {
+        const int nt = min(tgroup, taps - t0), rows = nt * nci;
+        __syncthreads();
+        for (int idx = tid; idx < rows * 32; idx += SISR_BLOCK) {
+            const int row = idx >> 5, c = idx & 31;
+            const int tl = row / nci, cl = row - tl * nci, tap = t0 + tl;
+            const int cp = cot * 32 + c;
+            int64_t prow;
+            if (w.layout == 1) prow = (int64_t)(chunk * taps + tap) * 32 + cl;
+            else { const int r = tap / w.KW, sx = tap - r * w.KW; prow = (int64_t)(chunk * w.KH + r) * w.KROWP + sx * w.PS + cl; }
+            lds[row * 33 + c] = cp < w.CoutPad ? w.dwpk[prow * w.CoutPad + cp] : 0.f;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < rows * 32; idx += SISR_BLOCK) {
+            const int c = idx / rows, q = idx - c * rows;            // q runs over (cl, tap): contiguous in OIHW
+            const int cl = q / nt, tl = q - cl * nt;
+            const int cp = cot * 32 + c;
+            if (cp >= w.Cout) continue;
+            const int co = w.shuffle2 ? ((cp % Cq) * 4 + cp / Cq) : cp;
+            const int col = (ci0 + cl) * taps + t0 + tl;
+            const int64_t e = (int64_t)co * cols + col;
+            const float g = lds[(tl * nci + cl) * 33 + c];
+            if (MODE == 0) part += g * w.w_orig[e];
+            else w.grad[e] = w.u_used ? (g - gw * w.u_used[co] * w.v_used[col]) * inv : g;
+        }
+    }
+    return part;
+}
+
+__global__ void __launch_bounds__(SISR_BLOCK) weights_grad_dot_kernel(const SisrWeightGradDesc* table, float* dot_part) {
+    __shared__ float lds[WGT_ROWS * 33];
     __shared__ float scratch[8];
     const SisrWeightGradDesc w = table[blockIdx.x];
+    if ((int)blockIdx.y >= wgt_tiles(w)) return;
     float part = 0.f;
-    if (w.u_used != nullptr && w.grad != nullptr) {
-        const int64_t total = (int64_t)w.Cout * w.Cin * w.KH * w.KW;
-        for (int64_t e = (int64_t)blockIdx.y * SISR_BLOCK + threadIdx.x; e < total; e += (int64_t)WG_PARTS * SISR_BLOCK)
-            part += w.dwpk[wg_packed_index(w, e)] * w.w_orig[e];
-    }
+    if (w.u_used != nullptr && w.grad != nullptr) part = wgt_tile<0>(w, blockIdx.y, lds, 0.f, 0.f);
     const float tot = block_sum(part, scratch);
-    if (threadIdx.x == 0) dot_part[blockIdx.x * WG_PARTS + blockIdx.y] = tot;
+    if (threadIdx.x == 0) dot_part[(int64_t)blockIdx.x * gridDim.y + blockIdx.y] = tot;
 }
 
-__global__ void __launch_bounds__(SISR_BLOCK) weights_grad_kernel(const SisrWeightGradDesc* table,
-                                                                 const float* dot_part) {
-    const int WG_PARTS = gridDim.y;
+__global__ void __launch_bounds__(SISR_BLOCK) weights_grad_kernel(const SisrWeightGradDesc* table, const float* dot_part) {
+    __shared__ float lds[WGT_ROWS * 33];
     const SisrWeightGradDesc w = table[blockIdx.x];
-    const int tid = threadIdx.x;
-    const int cols = w.Cin * w.KH * w.KW;
-    const int64_t total = (int64_t)w.Cout * cols;
+    const int tid = threadIdx.x, n_tiles = wgt_tiles(w);
+    if ((int)blockIdx.y >= n_tiles) return;
     const int Cq = w.Cout >> 2;
     if (blockIdx.y == 0 && w.grad_bias != nullptr && w.dbias_pk != nullptr) {
         for (int co = tid; co < w.Cout; co += SISR_BLOCK)
             w.grad_bias[co] = w.dbias_pk[w.shuffle2 ? ((co & 3) * Cq + (co >> 2)) : co];
     }
     if (w.grad == nullptr) return;
-    const int64_t start = (int64_t)blockIdx.y * SISR_BLOCK + tid, stride = (int64_t)WG_PARTS * SISR_BLOCK;
-    if (w.u_used == nullptr) {
-        for (int64_t e = start; e < total; e += stride) w.grad[e] = w.dwpk[wg_packed_index(w, e)];
-        return;
+    float gw = 0.f, inv = 1.f;
+    if (w.u_used != nullptr) {
+        const float sigma = w.sigma[0];
+        float dot = 0.f;
+        for (int k = 0; k < n_tiles; ++k) dot += dot_part[(int64_t)blockIdx.x * gridDim.y + k];
+        gw = dot / sigma;          // <G, W> with W = W_orig / sigma
+        inv = 1.f / sigma;
     }
-    const float sigma = w.sigma[0];
-    float dot = 0.f;
-    for (int k = 0; k < WG_PARTS; ++k) dot += dot_part[blockIdx.x * WG_PARTS + k];
-    const float gw = dot / sigma;          // <G, W> with W = W_orig / sigma
-    const float inv = 1.f / sigma;
-    for (int64_t e = start; e < total; e += stride) {
-        const int co = (int)(e / cols), col = (int)(e - (int64_t)co * cols);
-        w.grad[e] = (w.dwpk[wg_packed_index(w, e)] - gw * w.u_used[co] * w.v_used[col]) * inv;
-    }
+    wgt_tile<1>(w, blockIdx.y, lds, gw, inv);
 }
 
 static int parts_for(int64_t elems) {           // workgroups per weight for the element-wise multi-tensor kernels
@@ -345,11 +366,9 @@ extern "C" int sisr_weights_prepare(const SisrWeightDesc* table_dev, int32_t n, 
     return 0;
 }
 
-extern "C" int sisr_weights_grad_parts(int64_t max_elems) { return parts_for(max_elems); }
-
 extern "C" int sisr_weights_grad(const SisrWeightGradDesc* table_dev, int32_t n, float* dot_work, int32_t parts,
                                  void* stream) {
-    if (!table_dev || n <= 0 || !dot_work || parts <= 0) return SISR_E_BADARG;
+    if (!table_dev || n <= 0 || !dot_work || parts <= 0 || parts > 65535) return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(weights_grad_dot_kernel, dim3(n, parts), dim3(SISR_BLOCK), 0, st, table_dev, dot_work);
     SISR_CHECK_LAUNCH();

@@ -468,7 +468,10 @@ class WeightGradBatch:
             t.layout = 1 if p.kinds[2] else 0
             res[id(p.ref)] = (gw, gb)
         tab = _table_to_device(table, dev)
-        parts = lib.sisr_weights_grad_parts(max(p.ref.weight.numel() for p, _, _, _ in self.items))
+        def tiles(t):                      # tiles of one weight: 32 packed couts x one channel chunk
+            ck = 32 if t.layout == 1 else t.CK
+            return ((t.Cout + 31) // 32) * ((t.Cin + ck - 1) // ck)
+        parts = max(tiles(t) for t in table)
         work = torch.empty((parts * len(self.items),), dtype=torch.float32, device=dev)
         L.check(lib.sisr_weights_grad(tab.data_ptr(), len(self.items), work.data_ptr(), parts, _stream()),
                 'sisr_weights_grad')
