@@ -151,7 +151,7 @@ typedef struct SisrWeightDesc {
     float *u, *v;             /* spectral-norm buffers (updated in place when training) or NULL */
     float *u_used, *v_used;   /* copies of the u/v that define sigma (for backward) or NULL   */
     float *sigma;             /* [1] out (1.0 when u == NULL)                                 */
-    float *sn_work;           /* power-iteration scratch, >= ceil(Cout/64)*Cin*KH*KW + Cout floats (u != NULL) */
+    float *sn_work;           /* power-iteration scratch, >= ceil(Cout/16)*Cin*KH*KW + Cout floats (u != NULL) */
     float *wpk_fwd;           /* packed W/sigma for the forward conv, or NULL                 */
     float *wpk_dgrad;         /* packed flipped/transposed W/sigma for the data gradient, or NULL */
     int32_t Cout, Cin, KH, KW;

@@ -15,12 +15,12 @@
 
 // Power iteration in four short multi-tensor launches (grid = (weights, jobs); surplus workgroups exit), so
 // the 512x4608 matrices of the discriminator are spread over the chip instead of one workgroup per matrix:
-//   A  t_part[rb][j] = sum_{i in row block rb} W[i][j] u[i]        (workgroup = 64 rows x 1024 columns)
-//   B  t = sum_rb t_part ; v = t / max(|t|, eps)                   (one workgroup per weight)
-//   C  s[i] = W[i,:] . v                                           (wave per row, 4 rows per workgroup)
-//   D  u = s / max(|s|, eps) ; sigma = u . s                       (one workgroup per weight)
-// Evaluation mode skips A/B (v is kept) and D keeps the stored u.  sn_work per weight: [RB][cols] + [rows] floats.
-#define SN_RB 64
+//   A  t_part[rb][j] = sum_{i in row block rb} W[i][j] u[i]        (workgroup = 16 rows x 1024 columns)
+//   B  t = sum_rb t_part                                           (thread per column)
+//   C  s'[i] = W[i,:] . t                                          (wave per row, 4 rows per workgroup)
+//   D  v = t / max(|t|, eps) ; s = s' / max(|t|, eps) ; u = s / max(|s|, eps) ; sigma = u . s   (one workgroup per weight)
+// Evaluation mode skips A/B (C uses the stored v) and D keeps the stored u.  sn_work per weight: [RB][cols] + [rows] floats.
+#define SN_RB 16
 #define SN_CB 1024
 __device__ __forceinline__ int sn_rblocks(int rows) { return (rows + SN_RB - 1) / SN_RB; }
 
@@ -55,31 +55,19 @@ __global__ void __launch_bounds__(SISR_BLOCK) sn_wt_u_kernel(const SisrWeightDes
     }
 }
 
-__global__ void __launch_bounds__(SISR_BLOCK) sn_v_finish_kernel(const SisrWeightDesc* table) {
-    __shared__ float scratch[8];
+__global__ void __launch_bounds__(SISR_BLOCK) sn_t_sum_kernel(const SisrWeightDesc* table) {
     const SisrWeightDesc w = table[blockIdx.x];
-    if (w.u == nullptr) return;
-    const int rows = w.Cout, cols = w.Cin * w.KH * w.KW, tid = threadIdx.x;
-    if (!w.training) {
-        if (w.v_used) for (int j = tid; j < cols; j += SISR_BLOCK) w.v_used[j] = w.v[j];
-        return;
-    }
+    if (w.u == nullptr || !w.training) return;
+    const int rows = w.Cout, cols = w.Cin * w.KH * w.KW;
+    const int j = blockIdx.y * SISR_BLOCK + threadIdx.x;
+    if (j >= cols) return;
     const int nrb = sn_rblocks(rows);
-    float part = 0.f;
-    for (int j = tid; j < cols; j += SISR_BLOCK) {
-        float t = 0.f;
-        for (int rb = 0; rb < nrb; ++rb) t += w.sn_work[(int64_t)rb * cols + j];
-        w.sn_work[j] = t;                               // row block 0 now holds the full sum
-        part += t * t;
-    }
-    const float iv = 1.f / fmaxf(sqrtf(block_sum(part, scratch)), SN_EPS);
-    for (int j = tid; j < cols; j += SISR_BLOCK) {
-        const float v = w.sn_work[j] * iv;
-        w.v[j] = v;
-        if (w.v_used) w.v_used[j] = v;
-    }
+    float t = 0.f;
+    for (int rb = 0; rb < nrb; ++rb) t += w.sn_work[(int64_t)rb * cols + j];
+    w.sn_work[j] = t;                                   // row block 0 now holds t = W^T u (not yet normalised)
 }
 
+// s' = W t (training; the 1/|t| factor is applied by the finishing kernel) or s = W v (evaluation)
 __global__ void __launch_bounds__(SISR_BLOCK) sn_w_v_kernel(const SisrWeightDesc* table) {
     const SisrWeightDesc w = table[blockIdx.x];
     if (w.u == nullptr) return;
@@ -87,8 +75,9 @@ __global__ void __launch_bounds__(SISR_BLOCK) sn_w_v_kernel(const SisrWeightDesc
     const int lane = threadIdx.x & 63, i = blockIdx.y * (SISR_BLOCK / 64) + (threadIdx.x >> 6);
     if (i >= rows) return;
     const float* wr = w.w_orig + (int64_t)i * cols;
+    const float* vec = w.training ? w.sn_work : w.v;
     float a = 0.f;
-    for (int j = lane; j < cols; j += 64) a += wr[j] * w.v[j];
+    for (int j = lane; j < cols; j += 64) a += wr[j] * vec[j];
     a = wave_sum(a);
     if (lane == 0) w.sn_work[(int64_t)sn_rblocks(rows) * cols + i] = a;
 }
@@ -103,16 +92,28 @@ __global__ void __launch_bounds__(SISR_BLOCK) sn_u_finish_kernel(const SisrWeigh
     }
     const int rows = w.Cout, cols = w.Cin * w.KH * w.KW;
     const float* s = w.sn_work + (int64_t)sn_rblocks(rows) * cols;
-    float iu = 0.f;
+    float iv = 1.f, iu = 0.f;
     if (w.training) {
+        // v = t / max(|t|, eps) ; s = W v = s' / max(|t|, eps) ; u = s / max(|s|, eps)
         float part = 0.f;
-        for (int i = tid; i < rows; i += SISR_BLOCK) part += s[i] * s[i];
+        for (int j = tid; j < cols; j += SISR_BLOCK) part += w.sn_work[j] * w.sn_work[j];
+        iv = 1.f / fmaxf(sqrtf(block_sum(part, scratch)), SN_EPS);
+        for (int j = tid; j < cols; j += SISR_BLOCK) {
+            const float v = w.sn_work[j] * iv;
+            w.v[j] = v;
+            if (w.v_used) w.v_used[j] = v;
+        }
+        part = 0.f;
+        for (int i = tid; i < rows; i += SISR_BLOCK) { const float si = s[i] * iv; part += si * si; }
         iu = 1.f / fmaxf(sqrtf(block_sum(part, scratch)), SN_EPS);
+    } else if (w.v_used) {
+        for (int j = tid; j < cols; j += SISR_BLOCK) w.v_used[j] = w.v[j];
     }
     float part = 0.f;
     for (int i = tid; i < rows; i += SISR_BLOCK) {
-        const float u = w.training ? s[i] * iu : w.u[i];
-        part += u * s[i];
+        const float si = s[i] * iv;
+        const float u = w.training ? si * iu : w.u[i];
+        part += u * si;
         if (w.training) w.u[i] = u;
         if (w.u_used) w.u_used[i] = u;
     }
@@ -283,27 +284,58 @@ __device__ __forceinline__ float wgt_tile(const SisrWeightGradDesc& w, int tile,
     for (int t0 = 0; t0 < taps; t0 += tgroup) {
         const int nt = min(tgroup, taps - t0), rows = nt * nci;
         __syncthreads();
-        for (int idx = tid; idx < rows * 32; idx += SISR_BLOCK) {
-            const int row = idx >> 5, c = idx & 31;
-            const int tl = row / nci, cl = row - tl * nci, tap = t0 + tl;
-            const int cp = cot * 32 + c;
-            int64_t prow;
-            if (w.layout == 1) prow = (int64_t)(chunk * taps + tap) * 32 + cl;
-            else { const int r = tap / w.KW, sx = tap - r * w.KW; prow = (int64_t)(chunk * w.KH + r) * w.KROWP + sx * w.PS + cl; }
-            lds[row * 33 + c] = cp < w.CoutPad ? w.dwpk[prow * w.CoutPad + cp] : 0.f;
+        // 4 independent 128-byte-coalesced loads in flight per thread before the LDS stores (the tile is otherwise
+        // one memory latency per 8 rows)
+        for (int idx0 = tid; idx0 < rows * 32; idx0 += 4 * SISR_BLOCK) {
+            float val[4];
+            int off[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = idx0 + k * SISR_BLOCK;
+                val[k] = 0.f; off[k] = -1;
+                if (idx < rows * 32) {
+                    const int row = idx >> 5, c = idx & 31;
+                    const int tl = row / nci, cl = row - tl * nci, tap = t0 + tl;
+                    const int cp = cot * 32 + c;
+                    int64_t prow;
+                    if (w.layout == 1) prow = (int64_t)(chunk * taps + tap) * 32 + cl;
+                    else { const int r = tap / w.KW, sx = tap - r * w.KW; prow = (int64_t)(chunk * w.KH + r) * w.KROWP + sx * w.PS + cl; }
+                    off[k] = row * 33 + c;
+                    if (cp < w.CoutPad) val[k] = w.dwpk[prow * w.CoutPad + cp];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (off[k] >= 0) lds[off[k]] = val[k];
         }
         __syncthreads();
-        for (int idx = tid; idx < rows * 32; idx += SISR_BLOCK) {
-            const int c = idx / rows, q = idx - c * rows;            // q runs over (cl, tap): contiguous in OIHW
-            const int cl = q / nt, tl = q - cl * nt;
-            const int cp = cot * 32 + c;
-            if (cp >= w.Cout) continue;
-            const int co = w.shuffle2 ? ((cp % Cq) * 4 + cp / Cq) : cp;
-            const int col = (ci0 + cl) * taps + t0 + tl;
-            const int64_t e = (int64_t)co * cols + col;
-            const float g = lds[(tl * nci + cl) * 33 + c];
-            if (MODE == 0) part += g * w.w_orig[e];
-            else w.grad[e] = w.u_used ? (g - gw * w.u_used[co] * w.v_used[col]) * inv : g;
+        for (int idx0 = tid; idx0 < rows * 32; idx0 += 4 * SISR_BLOCK) {
+            float g[4], wv[4];
+            int64_t e[4];
+            int co_[4], col_[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = idx0 + k * SISR_BLOCK;
+                e[k] = -1; g[k] = wv[k] = 0.f; co_[k] = col_[k] = 0;
+                if (idx < rows * 32) {
+                    const int c = idx / rows, q = idx - c * rows;        // q runs over (cl, tap): contiguous in OIHW
+                    const int cl = q / nt, tl = q - cl * nt;
+                    const int cp = cot * 32 + c;
+                    if (cp < w.Cout) {
+                        co_[k] = w.shuffle2 ? ((cp % Cq) * 4 + cp / Cq) : cp;
+                        col_[k] = (ci0 + cl) * taps + t0 + tl;
+                        e[k] = (int64_t)co_[k] * cols + col_[k];
+                        g[k] = lds[(tl * nci + cl) * 33 + c];
+                        if (MODE == 0) wv[k] = w.w_orig[e[k]];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (e[k] < 0) continue;
+                if (MODE == 0) part += g[k] * wv[k];
+                else w.grad[e[k]] = w.u_used ? (g[k] - gw * w.u_used[co_[k]] * w.v_used[col_[k]]) * inv : g[k];
+            }
         }
     }
     return part;
@@ -354,7 +386,7 @@ extern "C" int sisr_weights_prepare(const SisrWeightDesc* table_dev, int32_t n, 
     const int jobs_a = ((max_rows + SN_RB - 1) / SN_RB) * ((max_cols + SN_CB - 1) / SN_CB);
     hipLaunchKernelGGL(sn_wt_u_kernel, dim3(n, jobs_a), dim3(SISR_BLOCK), 0, st, table_dev);
     SISR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sn_v_finish_kernel, dim3(n), dim3(SISR_BLOCK), 0, st, table_dev);
+    hipLaunchKernelGGL(sn_t_sum_kernel, dim3(n, (max_cols + SISR_BLOCK - 1) / SISR_BLOCK), dim3(SISR_BLOCK), 0, st, table_dev);
     SISR_CHECK_LAUNCH();
     hipLaunchKernelGGL(sn_w_v_kernel, dim3(n, (max_rows + 3) / 4), dim3(SISR_BLOCK), 0, st, table_dev);
     SISR_CHECK_LAUNCH();

@@ -208,8 +208,8 @@ def prepare_weights(items, training, need_dgrad=True):
         off_s = small
         rows_, cols_ = ref.geom.cout, ref.geom.cin * ref.geom.k * ref.geom.k
         small += 4 + (_align4(rows_) + _align4(cols_) if ref.u is not None else 0)
-        off_w = small                              # power-iteration scratch: [ceil(rows/64)][cols] + [rows]
-        small += _align4((rows_ + 63) // 64 * cols_ + rows_) if ref.u is not None else 0
+        off_w = small                              # power-iteration scratch: [ceil(rows/16)][cols] + [rows]
+        small += _align4((rows_ + 15) // 16 * cols_ + rows_) if ref.u is not None else 0
         metas.append((off_f, off_d, off_s, off_w))
     big = torch.empty(total, dtype=torch.float32, device=dev)
     sm = torch.empty(small, dtype=torch.float32, device=dev)
