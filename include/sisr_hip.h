@@ -57,8 +57,7 @@ typedef struct SisrConvPlan {
     int32_t msub, nsub;             /* 32x32 MFMA sub-tiles per wave (M) / per block (N)     */
     int32_t lds_bytes;
     int32_t wpk_elems;              /* elements in the packed weight buffer                  */
-    int32_t variant;                /* bf16 family: 0 generic (chunks of 32), 1 persistent
-                                       weights-resident kernel for Cin = 64 (one chunk of 64)  */
+    int32_t variant;                /* kernel variant within a family; 0 (the only one) -- reserved        */
     /* bf16 family: reciprocals m = ceil(2^32 / d) (0 for d = 1) so that n / d = umulhi(n, m) for n, d < 2^16 --
      * the kernels' index arithmetic (tile id, tile row, LDS row) without integer division */
     uint32_t m_tiles_x, m_thw, m_tw, m_iw, m_wrow;
@@ -170,7 +169,7 @@ typedef struct SisrWeightDesc {
     /* bf16 images for the bf16-MFMA kernels: [chunk of CK in-channels][cout][tap*CK + ci] (or NULL) */
     void *wbf_fwd, *wbf_dgrad;
     int32_t bf_f_CoutPad, bf_d_CoutPad;
-    int32_t bf_f_CK, bf_d_CK;   /* in-channel chunk of the bf16 images: 32 (generic) or 64 (persistent kernel) */
+    int32_t bf_f_CK, bf_d_CK;   /* in-channel chunk of the bf16 images (32) */
     void *wbf_dcls[4];          /* bf16 images of the stride-2 parity classes (chunks of 32), or NULL: then wpk_dcls */
     int32_t bf_c_CoutPad[4];
 } SisrWeightDesc;

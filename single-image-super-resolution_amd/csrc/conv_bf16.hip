@@ -408,12 +408,7 @@ static int conv_bf16_lds_bytes(int BM, int TN, int TH, int TW, int S, int KH, in
     return BM * 4 + in_elems * 2 + w_bytes + 16;
 }
 
-extern "C" int sisr_conv2d_plan_bf16_persist(SisrConvDesc* d);
-extern "C" int sisr_conv2d_bf16_persist(const SisrConvDesc* d, void* stream);
-
 extern "C" int sisr_conv2d_plan_bf16(SisrConvDesc* d) {
-    // Cin = 64, stride 1: experimental persistent weights-resident kernel, opt-in (SISR_BF16_PERSIST=1)
-    if (d && getenv("SISR_BF16_PERSIST") && sisr_conv2d_plan_bf16_persist(d) == 0) return 0;
     if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0) return SISR_E_BADARG;
     if ((d->Cin % BF_CK) || d->KH * d->KW > 9) return SISR_E_UNSUPPORTED;
     if (d->stride != 1 && d->stride != 2) return SISR_E_BADARG;
@@ -498,7 +493,6 @@ static int launch_conv_bf16(const SisrConvDesc* d, hipStream_t st) {
 
 extern "C" int sisr_conv2d_bf16(const SisrConvDesc* d, void* stream) {
     if (!d || !d->x1 || !d->wpk || !d->y) return SISR_E_BADARG;
-    if (d->plan.variant == 1) return sisr_conv2d_bf16_persist(d, stream);
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
     if (d->stat_part && (!d->cnt_part || d->y_mode != SISR_Y_NHWC)) return SISR_E_BADARG;
     if (d->bnb_part && (d->y_mode != SISR_Y_NHWC || d->y_sy != 1 || d->y_sx != 1 || d->y_H != d->Ho || d->y_W != d->Wo ||
