@@ -75,50 +75,3 @@ extern "C" int sisr_struct_sizes(int32_t* out, int32_t cap) {
 
 extern "C" const char* sisr_version(void) { return "sisr_hip 0.1 (gfx950, fp32 MFMA path)"; }
 
-// ---- developer build only (make trace): LDS read-rate microbenchmark used to choose the tile strides -------
-#ifdef SISR_CONV_TRACE
-typedef short lb4 __attribute__((ext_vector_type(4)));
-typedef int lbi4 __attribute__((ext_vector_type(4)));
-typedef int lbi2 __attribute__((ext_vector_type(2)));
-// kind 0: ds_read_b64_tr_b16 with the wgrad lane pattern; 1: plain ds_read_b64, same addresses;
-// 2: ds_read_b128, lane = pixel (conv A-fragment pattern).  12 reads per iteration at pixel offsets 0..11.
-__global__ void __launch_bounds__(256) lds_bench_kernel(int kind, int ps, int iters, long long* out) {
-    extern __shared__ __attribute__((aligned(16))) short lb[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < 40 * 1024; i += 256) lb[i] = (short)i;
-    __syncthreads();
-    const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-    int off;
-    if (kind == 2) off = (lane & 31) * ps + 8 * (lane >> 5);
-    else off = (8 * (grp >> 1) + tq) * ps + 16 * (grp & 1) + 4 * tp;
-    int acc = 0;
-    unsigned ad[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) ad[k] = (unsigned)((off + k * ps) * 2);       // LDS byte addresses (lb at 0)
-    const long long t0 = clock64();
-    for (int it = 0; it < iters; ++it) {
-        // 12 reads issued back to back, one wait: measures issue/throughput, not latency
-        lbi2 v[12];
-        lbi4 w[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            if (kind == 0) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v[k]) : "v"(ad[k]));
-            else if (kind == 1) asm volatile("ds_read_b64 %0, %1" : "=v"(v[k]) : "v"(ad[k]));
-            else asm volatile("ds_read_b128 %0, %1" : "=v"(w[k]) : "v"(ad[k]));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int k = 0; k < 12; ++k) acc ^= (kind == 2) ? w[k][0] : v[k][0];
-    }
-    const long long t1 = clock64();
-    if (lane == 0) out[tid >> 6] = t1 - t0;
-    if (acc == 0x7fffffff) out[4] = acc;
-}
-
-extern "C" int sisr_lds_bench(int kind, int ps, int iters, long long* out_dev, void* stream) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_bench_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    hipLaunchKernelGGL(lds_bench_kernel, dim3(1), dim3(256), 80 * 1024, reinterpret_cast<hipStream_t>(stream), kind, ps, iters, out_dev);
-    SISR_CHECK_LAUNCH();
-    return 0;
-}
-#endif
