@@ -1,0 +1,110 @@
+"""GPU: the benchmark configuration at FULL size (BASELINE.json north_star: Generator(16, 64, 256, [2], use_sn=True),
+B=16, LR 96x96 -> SR 192x192), where the CPU oracle would take minutes.  Checked through size-independent properties
+of the path instead of reference values:
+  * determinism  -- every reduction on the path has a fixed order, so two runs are BIT-identical;
+  * linearity of the backward pass in the incoming gradient -- scaling grad_output by 2 (exact in fp32) must scale
+    every parameter gradient and the input gradient by exactly 2;
+  * batch-permutation equivariance -- training-mode BatchNorm statistics do not depend on the order of the patches,
+    so G(x[perm]) = G(x)[perm] and the parameter gradients agree (up to fp32 re-association of the per-tile
+    statistics, 2e-5 relative);
+  * per-sample finiteness and the tanh range of the output image.
+Both precision builds (exact-fp32 and bf16 matrix cores) must satisfy all of them."""
+import pytest
+import torch
+
+from gpu_helpers import pkg
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+B, LR = 16, 96
+
+
+def _run(net, mg, x, r, spectral_state):
+    """one training-mode forward+backward from a fixed spectral-norm / BatchNorm state"""
+    net.load_state_dict(spectral_state)
+    net.zero_grad(set_to_none=True)
+    xx = x.clone().requires_grad_(True)
+    out = net(xx)
+    (out * r).sum().backward()
+    return out.detach(), xx.grad.detach(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_full_size_generator_properties(precision):
+    E, mg = pkg('engine'), pkg('model_generator')
+    E.set_precision(precision)
+    try:
+        torch.manual_seed(0)
+        net = mg.Generator(16, 64, 256, [2], use_sn=True).cuda().train()
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        g = torch.Generator().manual_seed(11)
+        x = (torch.rand(B, 3, LR, LR, generator=g) * 2 - 1).cuda()
+        r = (torch.rand(B, 3, 2 * LR, 2 * LR, generator=g) * 2 - 1).cuda()
+        out, gx, grads = _run(net, mg, x, r, state)
+        assert tuple(out.shape) == (B, 3, 2 * LR, 2 * LR)
+        assert bool(torch.isfinite(out).all()) and float(out.abs().max()) <= 1.0           # tanh range
+        assert all(bool(torch.isfinite(v).all()) for v in grads.values()) and bool(torch.isfinite(gx).all())
+        # determinism: bit-identical replay
+        out2, gx2, grads2 = _run(net, mg, x, r, state)
+        assert torch.equal(out, out2) and torch.equal(gx, gx2)
+        assert all(torch.equal(grads[k], grads2[k]) for k in grads)
+        # linearity of the backward pass: 2 * grad_output -> exactly 2 * every gradient
+        _, gx3, grads3 = _run(net, mg, x, 2.0 * r, state)
+        assert torch.equal(gx3, 2.0 * gx)
+        assert all(torch.equal(grads3[k], 2.0 * grads[k]) for k in grads), \
+            [k for k in grads if not torch.equal(grads3[k], 2.0 * grads[k])][:5]
+        # batch-permutation equivariance (training-mode BatchNorm statistics are order-free)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
+        outp, gxp, gradsp = _run(net, mg, x[perm], r[perm], state)
+        tol = 2e-5 if precision == 'fp32' else 2e-2          # bf16: re-associated statistics flip a few roundings
+        assert rel_err(outp.cpu(), out[perm].cpu()) < tol
+        assert rel_err(gxp.cpu(), gx[perm].cpu()) < 50 * tol
+        big = max(float(v.abs().max()) for v in grads.values())
+        for k in grads:
+            scale = max(float(grads[k].abs().max()), 0.02 * big)
+            assert float((gradsp[k] - grads[k]).abs().max()) / scale < 50 * tol, k
+    finally:
+        E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_full_size_discriminator_and_vgg_properties(precision):
+    """SURVEY 8d cfg2 sizes: Discriminator on 16 x 3 x 96 x 96 with the reference's feature / stride lists
+    (config.py:81-82; fc_in = 18,432) and MaskedVGG(0b00010): determinism and backward linearity"""
+    E, md, mce = pkg('engine'), pkg('model_discriminator'), pkg('model_content_extractor')
+    E.set_precision(precision)
+    try:
+        torch.manual_seed(0)
+        net = md.Discriminator((3, 96, 96), [64, 64, 128, 128, 256, 256, 512, 512], [1, 2, 1, 2, 1, 2, 1, 2]).cuda().train()
+        ext = mce.MaskedVGG(0b00010, pretrained=False).cuda()
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        g = torch.Generator().manual_seed(12)
+        x = (torch.rand(16, 3, 96, 96, generator=g) * 2 - 1).cuda()
+        r = (torch.rand(16, 1, generator=g) * 2 - 1).cuda()
+
+        def run(scale):
+            net.load_state_dict(state)
+            net.zero_grad(set_to_none=True)
+            xx = x.clone().requires_grad_(True)
+            out = net(xx)
+            (out * (scale * r)).sum().backward()
+            return out.detach(), xx.grad.detach(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+        out, gx, grads = run(1.0)
+        assert tuple(out.shape) == (16, 1) and bool(((out > 0) & (out < 1)).all())           # sigmoid range
+        out2, gx2, grads2 = run(1.0)
+        assert torch.equal(out, out2) and torch.equal(gx, gx2) and all(torch.equal(grads[k], grads2[k]) for k in grads)
+        _, gx3, grads3 = run(2.0)
+        assert torch.equal(gx3, 2.0 * gx) and all(torch.equal(grads3[k], 2.0 * grads[k]) for k in grads)
+        # VGG22 features: deterministic, finite, and the input gradient is linear in the incoming gradient
+        xv = x.clone().requires_grad_(True)
+        f = ext(xv)
+        rv = torch.rand(f.shape, generator=torch.Generator().manual_seed(4)).cuda()
+        (f * rv).sum().backward()
+        g1 = xv.grad.clone()
+        xv2 = x.clone().requires_grad_(True)
+        f2 = ext(xv2)
+        (f2 * (2.0 * rv)).sum().backward()
+        assert torch.equal(f, f2) and bool(torch.isfinite(f).all()) and torch.equal(xv2.grad, 2.0 * g1)
+    finally:
+        E.set_precision('fp32')
