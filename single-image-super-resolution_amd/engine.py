@@ -7,13 +7,11 @@ leaky-relu slope (PReLU / LeakyReLU / ReLU) that its consumer applies while stag
 LDS, so BatchNorm / activation layers never make their own pass over HBM.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib as L
-
-
-import os
 
 # 'fp32': exact-fp32 MFMA everywhere (the parity build).  'bf16': layers with Cin % 32 == 0 run their
 # contraction on the bf16 matrix cores (fp32 accumulate, fp32 statistics, fp32 tensors in HBM).
