@@ -44,7 +44,7 @@ __device__ __forceinline__ void conv_kblock(const float* const (&ap)[MSUB], cons
 // TAG only changes the kernel SYMBOL: TAG 1 = the 3x3, 64->64, stride-1 trunk convolution of G (fwd and
 // dgrad, 66 identical launches per training step), so that profiler per-kernel averages refer to one shape.
 template <int MSUB, int NSUB, int TAG>
-__global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_f32_kernel(const SisrConvDesc d) {
+__global__ void __launch_bounds__(SISR_BLOCK, MSUB == 1 ? 3 : 2) conv_mfma_f32_kernel(const SisrConvDesc d) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const SisrConvPlan& p = d.plan;
     constexpr int BM = 4 * MSUB * 32, BN = NSUB * 32;
