@@ -245,22 +245,28 @@ __global__ void __launch_bounds__(SISR_BLOCK, MSUB == 1 ? 3 : 2) conv_mfma_f32_k
         if (tid == 0 && blockIdx.y == 0) d.cnt_part[blockIdx.x] = cnt;
     }
 
-    // residual / tanh flags are wave-uniform: hoisted out of the per-element loops
-    int ro[MSUB][16];
+    // output (and residual) through raw buffer accesses with 32-bit byte offsets: rows outside the image carry the
+    // out-of-range marker 2^31 (tensors are < 2 GB), so marker + channel offset is dropped by the hardware
+    unsigned rb[MSUB][16];
 #pragma unroll
     for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ro[ms][i] = row_off[wave * (MSUB * 32) + ms * 32 + mfma_row(i, lane)];
+        for (int i = 0; i < 16; ++i) {
+            const int o = row_off[wave * (MSUB * 32) + ms * 32 + mfma_row(i, lane)];
+            rb[ms][i] = o >= 0 ? (unsigned)o * 4u : 0x80000000u;
+        }
+    const unsigned ybytes = (unsigned)max(d.N * d.y_H * d.y_W, d.N * d.Ho * d.Wo) * (unsigned)d.Cout * 4u;
     if (d.res != nullptr) {
+        const __amdgpu_buffer_rsrc_t rr = sisr_rsrc(d.res, ybytes);
 #pragma unroll
-        for (int ms = 0; ms < MSUB; ++ms)
+        for (int ns = 0; ns < NSUB; ++ns)
+            if (col_ok[ns]) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (ro[ms][i] >= 0) {
+                for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
-                    for (int ns = 0; ns < NSUB; ++ns)
-                        if (col_ok[ns]) acc[ms][ns][i] += d.res[(int64_t)ro[ms][i] + col_off[ns]];
-                }
+                    for (int i = 0; i < 16; ++i)
+                        acc[ms][ns][i] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, rb[ms][i] + (unsigned)col_off[ns] * 4u, 0, 0));
+            }
     }
     if (d.epi_act == SISR_EPI_TANH) {
 #pragma unroll
@@ -270,15 +276,18 @@ __global__ void __launch_bounds__(SISR_BLOCK, MSUB == 1 ? 3 : 2) conv_mfma_f32_k
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[ms][ns][i] = tanhf(acc[ms][ns][i]);
     }
+    const __amdgpu_buffer_rsrc_t ry = sisr_rsrc(d.y, ybytes);
 #pragma unroll
-    for (int ms = 0; ms < MSUB; ++ms)
+    for (int ns = 0; ns < NSUB; ++ns)
+        if (col_ok[ns]) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (ro[ms][i] >= 0) {
+            for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
-                for (int ns = 0; ns < NSUB; ++ns)
-                    if (col_ok[ns]) d.y[(int64_t)ro[ms][i] + col_off[ns]] = acc[ms][ns][i];
-            }
+                for (int i = 0; i < 16; ++i) {
+                    const float val = acc[ms][ns][i];      // (scalar temporary: see conv_bf16.hip)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), ry, rb[ms][i] + (unsigned)col_off[ns] * 4u, 0, 0);
+                }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -302,7 +311,7 @@ extern "C" int sisr_conv2d_plan(SisrConvDesc* d) {
     SisrConvPlan& p = d->plan;
     std::memset(&p, 0, sizeof(p));
     const int64_t ypix = std::max((int64_t)d->N * d->y_H * d->y_W, (int64_t)d->N * d->Ho * d->Wo);
-    if (ypix * d->Cout >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 31))
+    if (ypix * d->Cout >= (1ll << 29) || (int64_t)d->N * d->H * d->W * d->Cin >= (1ll << 31))
         return SISR_E_TOOBIG;
     p.nsub = d->Cout <= 32 ? 1 : 2;
     const int BN = p.nsub * 32;

@@ -8,9 +8,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define BF_CK 32
 #define BF_PS 40
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_rsrc(const void* p, unsigned bytes) { return sisr_rsrc(p, bytes); }
 
 // float4 staging with the prologue fixed at compile time, bf16 LDS image.
 // Addressing is the cheap part by construction: a thread's items walk the tile in steps of `ppi` pixels, so

@@ -46,6 +46,11 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
     return t;
 }
 
+// raw buffer resource over [p, p + bytes): loads / stores take 32-bit byte offsets, out-of-range ones are dropped
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sisr_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
 // n / d for n, d < 2^16 with the host-side reciprocal m = ceil(2^32 / d) (0 encodes d = 1): one multiply-high
 // instead of the ~25-instruction integer division sequence
 __host__ __device__ __forceinline__ uint32_t fdiv_magic(int d) {
