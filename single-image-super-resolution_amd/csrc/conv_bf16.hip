@@ -505,10 +505,16 @@ extern "C" int sisr_conv2d_bf16(const SisrConvDesc* d, void* stream) {
     if (p.CK != BF_CK || p.PS != BF_PS || p.n_tiles <= 0 || p.lds_bytes <= 0 || p.lds_bytes > 160 * 1024)
         return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // TAG only names the symbol (same code): 1 = the generator's trunk geometry in its forward role (BatchNorm
+    // statistics epilogue) -- the launch bench.py's roofline probe times --, 2 = the trunk geometry in its other
+    // roles (data gradients), 0 = everything else; profiles then report the roles separately
     const bool trunk = d->Cin == 64 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1;
-    if (p.msub == 2 && p.nsub == 2) return trunk ? launch_conv_bf16<2, 2, 1>(d, st) : launch_conv_bf16<2, 2, 0>(d, st);
+    const int tag = !trunk ? 0 : (d->stat_part ? 1 : 2);
+    if (p.msub == 2 && p.nsub == 2)
+        return tag == 1 ? launch_conv_bf16<2, 2, 1>(d, st) : tag == 2 ? launch_conv_bf16<2, 2, 2>(d, st) : launch_conv_bf16<2, 2, 0>(d, st);
     if (p.msub == 2 && p.nsub == 1) return launch_conv_bf16<2, 1, 0>(d, st);
-    if (p.msub == 1 && p.nsub == 2) return trunk ? launch_conv_bf16<1, 2, 1>(d, st) : launch_conv_bf16<1, 2, 0>(d, st);
+    if (p.msub == 1 && p.nsub == 2)
+        return tag == 1 ? launch_conv_bf16<1, 2, 1>(d, st) : tag == 2 ? launch_conv_bf16<1, 2, 2>(d, st) : launch_conv_bf16<1, 2, 0>(d, st);
     if (p.msub == 1 && p.nsub == 1) return launch_conv_bf16<1, 1, 0>(d, st);
     return SISR_E_BADARG;
 }
