@@ -87,7 +87,7 @@ def test_training_iteration_runs_in_bf16_mode(bf16_engine):
 def test_bf16_mode_trains_like_the_fp32_build():
     """30 Adam steps of the benchmark objective (10 * MSE to the HR patch, lr 1e-3) on a fixed batch, once per
     precision build from the same initial state: the loss must fall in both and the bf16 trajectory must stay
-    within 3 % of the fp32 one at every step (bf16 rounds MFMA operands only; accumulation, BatchNorm statistics,
+    within 1 % of the fp32 one at every step (measured: 0.04 %) (bf16 rounds MFMA operands only; accumulation, BatchNorm statistics,
     parameters and the optimizer are fp32)."""
     E, mg, ut, op = pkg('engine'), pkg('model_generator'), pkg('utils'), pkg('optim')
     torch.manual_seed(0)
@@ -115,4 +115,4 @@ def test_bf16_mode_trains_like_the_fp32_build():
         E.set_precision('fp32')
     a, b = traj['fp32'], traj['bf16']
     assert a[-1] < 0.7 * a[0] and b[-1] < 0.7 * b[0], (a[0], a[-1], b[0], b[-1])
-    assert max(abs(x - y) / x for x, y in zip(a, b)) < 0.03, [round(abs(x - y) / x, 4) for x, y in zip(a, b)]
+    assert max(abs(x - y) / x for x, y in zip(a, b)) < 0.01, [round(abs(x - y) / x, 4) for x, y in zip(a, b)]
