@@ -55,29 +55,16 @@ def make_step(device, rank, world):
         loss.backward()
         return loss
 
-    state = {'graph': None, 'loss': None}
+    state = {'graphed': None}
 
     def capture():
-        """Record the forward+backward launch sequence (~350 kernels) once into a HIP graph; afterwards a step
-        replays it -- same kernels, same work, no per-launch host cost.  Gradients are static tensors of the
-        graph's pool; the gradient all-reduce and the Adam step stay ordinary stream work after the replay."""
-        side = torch.cuda.Stream(device=device)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                fwd_bwd()
-        torch.cuda.current_stream().wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            state['loss'] = fwd_bwd()
-        state['graph'] = g
+        """Record the forward+backward launch sequence (~350 kernels) once into a HIP graph (graph.GraphedStep);
+        afterwards a step replays it -- same kernels, same work, no per-launch host cost.  Gradients are static
+        tensors of the graph's pool; the gradient all-reduce and the Adam step stay ordinary stream work."""
+        state['graphed'] = sub('graph').GraphedStep(fwd_bwd)
 
     def step():
-        if state['graph'] is not None:
-            state['graph'].replay()
-            loss = state['loss']
-        else:
-            loss = fwd_bwd()
+        loss = state['graphed']() if state['graphed'] is not None else fwd_bwd()
         if reducer is not None:
             reducer.all_reduce_mean()
         opt.step()

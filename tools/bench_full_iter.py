@@ -21,7 +21,38 @@ hr = (torch.rand(B, 3, HR, HR, device=dev) * 2 - 1)
 ones, red, zeros = torch.ones(B, device=dev), torch.full((B,), .9, device=dev), torch.zeros(B, device=dev)
 
 
+def d_part():                       # train.py:45-74: G forward, D on real and on detached fake, backward
+    lr = ut.lr_from_hr(hr, (LR, LR), device=dev)
+    fake = net_g(lr)
+    net_d.zero_grad()
+    err_d = crit(net_d(hr).view(-1), red) + crit(net_d(fake.detach()).view(-1), zeros)
+    err_d.backward()
+    return err_d
+
+
+def g_part():                       # train.py:82-107: D on fake with the UPDATED D, VGG content loss, backward
+    lr = ut.lr_from_hr(hr, (LR, LR), device=dev)
+    fake = net_g(lr)
+    net_g.zero_grad()
+    err_g = crit(net_d(fake).view(-1), ones) * 5e-2 + torch.mean(torch.pow(ext(hr) - ext(fake), 2))
+    err_g.backward()
+    return err_g
+
+
+GRAPH = os.environ.get('GRAPH', '0') == '1'       # GRAPH=1: the two halves replayed from HIP graphs
+if GRAPH:
+    # the G step re-runs the generator forward (its graph must own the autograd state it differentiates), which the
+    # eager sequence shares with the D step: the graphed iteration does ~0.4 ms more GPU work and no host work
+    d_graph, g_graph = sub('graph').GraphedStep(d_part), sub('graph').GraphedStep(g_part)
+
+
 def iteration():
+    if GRAPH:
+        err_d = d_graph()
+        od.step()
+        err_g = g_graph()
+        og.step()
+        return err_d, err_g
     lr = ut.lr_from_hr(hr, (LR, LR), device=dev)
     fake = net_g(lr)
     net_d.zero_grad()
@@ -44,4 +75,4 @@ for _ in range(n):
     iteration()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
-print('full SRGAN iteration (eager launches, %s mode, B%d HR%d): %.2f ms  = %.0f HR patches/s' % (prec, B, HR, dt * 1e3, B / dt))
+print('full SRGAN iteration (%s, %s mode, B%d HR%d): %.2f ms  = %.0f HR patches/s' % ('HIP-graph replay' if GRAPH else 'eager launches', prec, B, HR, dt * 1e3, B / dt))
