@@ -323,6 +323,9 @@ int sisr_struct_sizes(int32_t *out, int32_t cap);
 int sisr_device_info(int32_t *n_cu, int32_t *lds_per_cu, char *arch, int32_t arch_len);
 int sisr_mfma_selftest(float *out_dev /* >= 32*32 floats */, void *stream);
 int sisr_tr16_selftest(int16_t *out_dev /* >= 64*8 shorts */, void *stream);
+/* fetch-and-clear the calling thread's pending HIP error (e.g. after an abandoned stream capture) so that it is
+ * not attributed to the next launch; returns the code that was pending (0: none) */
+int sisr_clear_last_error(void);
 const char *sisr_version(void);
 
 #ifdef __cplusplus

@@ -126,6 +126,7 @@ _SIGS = {
     'sisr_struct_sizes': [C.POINTER(_i32), _i32],
     'sisr_device_info': [C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32],
     'sisr_mfma_selftest': [_f, _f],
+    'sisr_clear_last_error': [],
 }
 EXPORTS = sorted(list(_SIGS) + ['sisr_version'])
 

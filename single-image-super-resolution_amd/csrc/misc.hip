@@ -73,5 +73,10 @@ extern "C" int sisr_struct_sizes(int32_t* out, int32_t cap) {
     return 6;
 }
 
+// hipGetLastError() is per host thread and sticky until fetched: a failed stream capture (or any other failed
+// runtime call made by the host framework) leaves its code behind and the next kernel launch of this library
+// would report it as its own.  Returns the error that was pending (0: none) and clears it.
+extern "C" int sisr_clear_last_error(void) { return (int)hipGetLastError(); }
+
 extern "C" const char* sisr_version(void) { return "sisr_hip 0.1 (gfx950, fp32 MFMA path)"; }
 

@@ -274,16 +274,19 @@ def prepare_weights(items, training, need_dgrad=True):
     return out, (big, sm, tab_dev)
 
 
-_PIN_RING = {'buf': None, 'off': 0}
+_PIN_RING = {'buf': None, 'off': 0, 'half': 0, 'events': [None, None]}
 _PIN_CAPTURE = {'buf': None, 'off': 0}   # bump allocator for tables referenced by captured graphs
 _PIN_KEEP = []                           # ... whose pinned storage must outlive every replay
+_PIN_RING_BYTES = 4 << 20
 
 
 def _table_to_device(table, dev):
     """Descriptor table -> device without a host synchronisation: staged in pinned memory and copied
-    asynchronously on the current stream.  Eager mode uses a 4 MB pinned ring (a slot is reused only
-    thousands of launches later); under HIP-graph capture every table gets its own pinned buffer that is
-    kept alive forever, because the captured copy node re-reads it on each replay."""
+    asynchronously on the current stream.  Eager mode uses a 4 MB pinned ring in two halves: the last copy issued
+    from a half is followed by an event, and the host waits for that event before it writes into the half again
+    (normally long complete: a half holds thousands of tables), so a slot is never rewritten while its copy may
+    still be pending however far the GPU lags behind the host.  Under HIP-graph capture every table gets its own
+    pinned buffer that is kept alive forever, because the captured copy node re-reads it on each replay."""
     raw = bytes(table)
     n = (len(raw) + 255) & ~255
     if torch.cuda.is_current_stream_capturing():
@@ -294,16 +297,27 @@ def _table_to_device(table, dev):
             _PIN_KEEP.append(cap['buf'])
         host = cap['buf'][cap['off']:cap['off'] + n]
         cap['off'] += n
-    else:
-        ring = _PIN_RING
-        if ring['buf'] is None:
-            ring['buf'] = torch.empty(4 << 20, dtype=torch.uint8, pin_memory=True)
-            _PIN_CAPTURE['buf'] = torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True)   # allocated OUTSIDE capture
-            _PIN_KEEP.append(_PIN_CAPTURE['buf'])
-        if ring['off'] + n > ring['buf'].numel():
-            ring['off'] = 0
-        host = ring['buf'][ring['off']:ring['off'] + n]
-        ring['off'] += n
+        host[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        return host.to(dev, non_blocking=True)
+    ring = _PIN_RING
+    if ring['buf'] is None:
+        ring['buf'] = torch.empty(_PIN_RING_BYTES, dtype=torch.uint8, pin_memory=True)
+        _PIN_CAPTURE['buf'] = torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True)   # allocated OUTSIDE capture
+        _PIN_KEEP.append(_PIN_CAPTURE['buf'])
+    half_bytes = _PIN_RING_BYTES // 2
+    assert n <= half_bytes, 'descriptor table larger than half the pinned ring'
+    if ring['off'] + n > (ring['half'] + 1) * half_bytes:          # this half is full: fence it, move to the other
+        ev = torch.cuda.Event()
+        ev.record()                                                 # after every copy issued from the full half
+        ring['events'][ring['half']] = ev
+        ring['half'] ^= 1
+        ring['off'] = ring['half'] * half_bytes
+        pending = ring['events'][ring['half']]
+        if pending is not None:
+            pending.synchronize()                                   # copies out of the half we are about to rewrite
+            ring['events'][ring['half']] = None
+    host = ring['buf'][ring['off']:ring['off'] + n]
+    ring['off'] += n
     host[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
     return host.to(dev, non_blocking=True)
 

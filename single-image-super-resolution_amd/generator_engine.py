@@ -127,8 +127,10 @@ def run_forward(topo, x, training):
     return out, sv
 
 
-def run_backward(sv, grad_out, need_dx):
-    """Returns ({id(param): grad}, grad_x or None)."""
+def run_backward(sv, grad_out, need_dx, sink=None, params=()):
+    """Returns ({id(param): grad}, grad_x or None).  sink (distributed.GradReducer or None): gradients are announced
+    to it in buckets as they become final -- after the output / upscale / trunk-end convs, after every
+    SINK_BLOCKS residual blocks, after the first conv -- so their all-reduce overlaps the rest of this schedule."""
     if not sv.training:
         raise NotImplementedError('backward through an eval-mode (running-statistics) generator forward '
                                   'is not implemented in the HIP path')
@@ -137,6 +139,23 @@ def run_backward(sv, grad_out, need_dx):
     grad_out = grad_out.contiguous()
     grads = {}
     wg = E.WeightGradBatch()
+    by_id = {id(p): p for p in params}
+    announced = set()
+    all_refs = [r for r in topo.conv_refs() if r is not None]
+
+    def flush(tag):
+        """un-pack the weight gradients collected so far (one launch) and announce every new gradient to the sink"""
+        for ref_id, (gw, gb) in wg.run().items():
+            ref = next(r for r in all_refs if id(r) == ref_id)
+            if gw is not None:
+                grads[id(ref.weight)] = gw
+            if gb is not None:
+                grads[id(ref.bias)] = gb
+        wg.items = []
+        if sink is not None:
+            new = [k for k in grads if k not in announced and k in by_id]
+            announced.update(new)
+            sink.ready([(by_id[k], grads[k]) for k in new], tag)
 
     def conv_bwd(ref, x_op, dy_op, need_dgrad=True, res=None, y_mode=L.Y_NHWC, bnb=None):
         """weight gradient (batched un-packing at the end) + data gradient.  bnb = (x, consts, slope) names the
@@ -191,6 +210,8 @@ def run_backward(sv, grad_out, need_dx):
         g, part = conv_bwd(topo.trunk_end, xl_op, dy, bnb=(rblocks[0][1].c2, rblocks[0][1].k2, None))
     else:
         g = conv_bwd(topo.trunk_end, xl_op, dy)
+    if sink is not None:
+        flush('tail')
     # ---- residual blocks, last to first ----------------------------------------------------------------
     for bi, (b, rec) in enumerate(rblocks):
         q2, dgam, dbet, _ = E.bn_backward(g, rec.c2, rec.k2, b['bn2'].weight, part=part)
@@ -210,6 +231,8 @@ def run_backward(sv, grad_out, need_dx):
             g, part = conv_bwd(b['c1'], in_op, dy1, res=g, bnb=(nrec.c2, nrec.k2, None))
         else:
             g = conv_bwd(b['c1'], in_op, dy1, res=g)
+        if sink is not None and (bi + 1) % SINK_BLOCKS == 0 and bi + 1 < len(rblocks):
+            flush('blocks%d' % (bi + 1))
     # ---- first conv + PReLU -----------------------------------------------------------------------------
     g_t0 = E.add(g, g_t) if topo.long_skip else g
     if topo.first_prelu.requires_grad:
@@ -217,34 +240,36 @@ def run_backward(sv, grad_out, need_dx):
     dy0 = Operand(g_t0, tuple(sv.t0_pre.shape), pro=L.PRO_ACT_BWD, x2=sv.t0_pre, slope=topo.first_prelu)
     x_op = Operand.plain(sv.x, dims=(n, sv.x.shape[2], sv.x.shape[3], sv.x.shape[1]), mode=L.X_NCHW)
     gx = conv_bwd(topo.first, x_op, dy0, need_dgrad=need_dx, y_mode=L.Y_NCHW)
-    for ref_id, (gw, gb) in wg.run().items():
-        ref = next(r for r in topo.conv_refs() if r is not None and id(r) == ref_id)
-        if gw is not None:
-            grads[id(ref.weight)] = gw
-        if gb is not None:
-            grads[id(ref.bias)] = gb
+    flush('final')
+    if sink is not None:
+        sink.backward_end()
     return grads, gx
+
+
+SINK_BLOCKS = 4          # residual blocks per announced gradient bucket (16 blocks: tail + 3 + final = 5 buckets)
 
 
 class GeneratorFunction(torch.autograd.Function):
     """autograd node for a whole generator forward: inputs (x, *parameters) -> image."""
 
     @staticmethod
-    def forward(ctx, topo, training, x, *params):
+    def forward(ctx, topo, training, sink, x, *params):
         out, sv = run_forward(topo, x, training)
-        ctx.sv, ctx.params = sv, params
+        ctx.sv, ctx.params, ctx.sink = sv, params, sink
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        grads, gx = run_backward(ctx.sv, grad_out, ctx.needs_input_grad[2])
+        grads, gx = run_backward(ctx.sv, grad_out, ctx.needs_input_grad[3], sink=ctx.sink, params=ctx.params)
         ctx.sv = None
-        return (None, None, gx) + tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
+        return (None, None, None, gx) + tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
 
 
 def generator_apply(topo, module, x):
     params = [p for p in module.parameters()]
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
-        return GeneratorFunction.apply(topo, module.training, x, *params)
+        # distributed.GradReducer.attach(module) leaves itself here: the backward schedule announces gradients to it
+        sink = getattr(module, '_sisr_grad_sink', None)
+        return GeneratorFunction.apply(topo, module.training, sink, x, *params)
     out, _ = run_forward(topo, x, module.training)
     return out

@@ -3,12 +3,15 @@
 constants, with ``MaskedVGG.forward`` on the gfx950 kernels (vgg_engine.py).
 
 Weights: the reference builds ``torchvision.models.vgg19(pretrained=True).features[:k]``
-(model_content_extractor.py:43), a remote fetch.  If torchvision and its weights are available they
-are loaded; otherwise (no network / no torchvision) the stack is initialised with torch's default
-Conv2d init under a fixed seed and a warning is printed -- load real weights with
-``load_state_dict`` (keys ``layers.<features index>.weight|bias``, as in the reference).
+(model_content_extractor.py:43), a remote fetch, and fails if that fails.  So does this drop-in:
+``MaskedVGG(mask)`` loads the torchvision weights (or the state_dict file named by
+``SISR_VGG19_WEIGHTS``: torchvision's ``vgg19`` checkpoint, keys ``features.<i>.weight|bias``) and
+RAISES when neither is available -- a content loss against random features would train silently
+wrong.  Only an explicit ``pretrained=False`` gives the seeded default initialisation (tests,
+benchmarks); load weights afterwards with ``load_state_dict`` (keys ``layers.<i>.weight|bias``, as
+in the reference).
 """
-import warnings
+import os
 
 import torch
 import torch.nn as nn
@@ -54,8 +57,10 @@ class MaskedVGG(nn.Module):
         torch.manual_seed(1234)
         self.layers = nn.Sequential(*_vgg19_feature_modules(self.intermediate_layers_kept[-1], width_div))
         torch.random.set_rng_state(gen_state)
-        if pretrained and width_div == 1:
-            self._try_load_torchvision()
+        if pretrained:
+            if width_div != 1:
+                raise ValueError('MaskedVGG: pretrained weights exist only for width_div=1')
+            self._load_pretrained()
         self.layers.eval()
         self.layers.requires_grad = False
         for param in self.layers.parameters():
@@ -70,14 +75,24 @@ class MaskedVGG(nn.Module):
                 pool_pending = True
         self._prog = VE.Program(convs, len(self.intermediate_layers_kept))
 
-    def _try_load_torchvision(self):
+    def _load_pretrained(self):
+        n = self.intermediate_layers_kept[-1]
+        path = os.environ.get('SISR_VGG19_WEIGHTS')
         try:
-            import torchvision.models as models
-            feats = models.vgg19(pretrained=True).features[:self.intermediate_layers_kept[-1]]
-            self.layers.load_state_dict(feats.state_dict(), strict=True)
+            if path:
+                sd = torch.load(path, map_location='cpu')
+                sd = {k[len('features.'):]: v for k, v in sd.items() if k.startswith('features.')} or sd
+                sd = {k: v for k, v in sd.items() if int(k.split('.')[0]) < n}
+            else:
+                import torchvision.models as models
+                sd = models.vgg19(pretrained=True).features[:n].state_dict()
+            self.layers.load_state_dict(sd, strict=True)
         except Exception as e:                                  # noqa: BLE001
-            warnings.warn('MaskedVGG: pretrained VGG19 weights unavailable (%s: %s); using a seeded default '
-                          'initialisation -- load real weights with load_state_dict' % (type(e).__name__, e))
+            raise RuntimeError(
+                'MaskedVGG(pretrained=True): the VGG19 weights could not be loaded (%s: %s).  The reference fails '
+                'here too (model_content_extractor.py:43).  Provide torchvision with its vgg19 checkpoint, or point '
+                'SISR_VGG19_WEIGHTS at a torchvision vgg19 state_dict file, or pass pretrained=False explicitly and '
+                'call load_state_dict yourself.' % (type(e).__name__, e)) from e
 
     def forward(self, x):
         return VE.vgg_apply(self._prog, x)

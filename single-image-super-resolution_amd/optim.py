@@ -25,6 +25,17 @@ class Adam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, **kw)
         self._tables = {}
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}                  # the cached descriptor tables point at the replaced moment tensors
+        for st in self.state.values():     # 'step' stays a host scalar (torch moves it to the parameter's device)
+            if isinstance(st.get('step'), torch.Tensor) and st['step'].is_cuda:
+                st['step'] = st['step'].cpu()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tables = {}
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -50,7 +61,11 @@ class Adam(torch.optim.Adam):
             beta1, beta2 = group['betas']
             for t, plist in by_step.items():
                 grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in plist]
-                key = (gi, tuple(p.data_ptr() for p in plist), tuple(g.data_ptr() for g in grads))
+                # the table holds raw pointers of parameters, gradients AND both moment tensors: load_state_dict()
+                # replaces the moments (same parameter / gradient addresses), so they are part of the key
+                key = (gi, tuple(p.data_ptr() for p in plist), tuple(g.data_ptr() for g in grads),
+                       tuple(self.state[p]['exp_avg'].data_ptr() for p in plist),
+                       tuple(self.state[p]['exp_avg_sq'].data_ptr() for p in plist))
                 cached = self._tables.get(gi)
                 if cached is None or cached[0] != key:
                     table = (L.AdamDesc * len(plist))()

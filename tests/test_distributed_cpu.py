@@ -1,13 +1,23 @@
 """CPU, world_size 2 over gloo: the data-parallel gradient exchange used for N > 1 (the RCCL path
-differs only in backend and streams).  Each rank holds a different gradient; after the exchange
-both hold the mean -- which for equal shards equals the reference's global-batch gradient."""
+differs only in backend and streams).
+  * post-backward form: each rank holds a different gradient; after the exchange both hold the mean;
+  * bucket-ready form (what the generator's backward schedule drives, generator_engine.run_backward): every
+    rank computes the ORACLE's gradients on its half of one golden batch (per-replica BatchNorm, like the
+    reference's DataParallel, config.py:114-118), announces them bucket by bucket in the schedule's order and
+    must end with the mean of the two per-shard gradients in every parameter;
+  * bench.py --gpus 2 starts two ranks by itself (launcher plumbing only, no GPU work)."""
 import importlib
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -27,23 +37,84 @@ def _worker(rank, world, port, q):
     params.append(torch.nn.Parameter(torch.randn(4), requires_grad=False))
     for i, p in enumerate(params[:-1]):
         p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
-    params[1].grad = None if False else params[1].grad           # keep: all have grads
-    red = mod.GradReducer(params, world, bucket_bytes=200)        # force several buckets
+    red = mod.GradReducer(params, world, bucket_bytes=200, inplace_bytes=1000)     # several buckets, one in-place tensor
     red.all_reduce_mean()
     ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params[:-1]))
     q.put((rank, ok, len(red.buckets)))
     dist.destroy_process_group()
 
 
-def test_grad_reducer_world2_gloo():
+def _run2(target, *extra):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, 2, port, q) + extra) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    return res
+
+
+def test_grad_reducer_world2_gloo():
+    res = _run2(_worker)
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] >= 2
+
+
+def _bucket_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, ROOT)
+    from helpers import load_case, oracle_fwd_bwd                      # the CPU oracle: checker only
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    mod = importlib.import_module('single-image-super-resolution_amd.distributed')
+    mg = importlib.import_module('single-image-super-resolution_amd.model_generator')
+    z, cfg, state, _, _ = load_case('gen_x2_nosn_w16')                 # B = 2: one patch per rank
+    x, r = torch.from_numpy(z['x']), torch.from_numpy(z['r'])
+    shard = [oracle_fwd_bwd(cfg, state, x[k:k + 1], r[k:k + 1])[2] for k in range(world)]     # both shards' gradients
+    want = {k: sum(s[k] for s in shard) / world for k in shard[0]}
+    net = mg.Generator(cfg['n_blocks'], cfg['nf'], cfg['nl'], cfg['list_scales'], use_sn=cfg['use_sn'])
+    net.load_state_dict(state, strict=True)
+    red = mod.GradReducer(net, world)                                  # attaches itself as the module's gradient sink
+    assert net._sisr_grad_sink is red
+    named = dict(net.named_parameters())
+    mine = {k: shard[rank][k].clone() for k in named}
+    # the schedule's announcement order (generator_engine.run_backward): output/upscale/trunk-end, blocks, first conv
+    order = [[k for k in named if k.startswith(('end.', 'upscale.', 'block_list_end.'))],
+             [k for k in named if k.startswith('block_list.')],
+             [k for k in named if k.startswith('first_layers.')]]
+    assert sorted(sum(order, [])) == sorted(named)
+    for tag, keys in zip(('tail', 'blocks4', mod.FINAL), order):
+        red.ready([(named[k], mine[k]) for k in keys], tag)
+    red.backward_end()
+    for k, p in named.items():
+        p.grad = mine[k]                                               # what autograd's AccumulateGrad does next
+    red.finish()                                                       # nothing left to reduce: all were announced
+    err = max(float((named[k].grad - want[k]).abs().max()) / max(float(want[k].abs().max()), 1e-12) for k in named)
+    q.put((rank, err, dict(red.stats)))
+    dist.destroy_process_group()
+
+
+def test_bucket_ready_interface_gives_the_mean_of_the_per_shard_oracle_gradients():
+    res = _run2(_bucket_worker)
+    for rank, err, stats in res:
+        assert err < 1e-6, (rank, err)
+        assert stats == {'early_buckets': 3, 'late_buckets': 0}, stats
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher environment must start two rank processes before any GPU call
+    (here: the launcher self-test, which all-reduces a 1 over the ranks on gloo and prints the count)"""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--dry-run-ranks'],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    rec = json.loads(line)
+    assert rec == {'dry_run': True, 'n_gpus': 2, 'world': 2}
+    # a launcher world size that contradicts --gpus is refused
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--dry-run-ranks'],
+                       capture_output=True, text=True, env=dict(env, WORLD_SIZE='2', RANK='0'), timeout=120, cwd=ROOT)
+    assert r.returncode == 2 and 'WORLD_SIZE=2' in r.stderr

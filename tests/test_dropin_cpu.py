@@ -10,12 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_dropin_aliases_expose_reference_names():
     code = (
-        "import model_generator, model_discriminator, model_content_extractor, model_generator_progressive, utils\n"
+        "import model_generator, model_discriminator, model_content_extractor, model_generator_progressive\n"
         "from model_generator import Generator, GeneratorSuffix\n"
         "from model_discriminator import Discriminator\n"
         "assert model_content_extractor.maxPool_indexes == (4, 9, 18, 27, 36)\n"
         "assert callable(model_content_extractor.identity) and callable(model_content_extractor.MaskedVGG)\n"
-        "assert callable(utils.lr_from_hr)\n"
         "g = GeneratorSuffix(Generator(1, 16, 64, [2]))\n"
         "assert g.n_features_last == 64 and isinstance(g.end, list)\n"
         "print('ok')\n")
@@ -38,6 +37,26 @@ def test_install_registers_reference_module_names():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_install_patches_lr_from_hr_without_shadowing_the_reference_utils(tmp_path):
+    """config.py / train.py use utils.save_and_show, utils.save_curr_vis and utils.SamplerRange besides lr_from_hr
+    (train.py:15,36; config.py:250,272): install() must leave those the reference's and replace only the hot function"""
+    (tmp_path / 'utils.py').write_text(
+        "def lr_from_hr(img_hr, image_size_lr, device='cpu'):\n    return 'reference'\n"
+        "def save_and_show(*a):\n    return 'ref-ui'\n"
+        "class SamplerRange:\n    pass\n")
+    code = (
+        "import importlib, utils\n"
+        "importlib.import_module('single-image-super-resolution_amd').install()\n"
+        "import utils as u2, model_generator\n"
+        "assert u2 is utils and utils.save_and_show() == 'ref-ui' and hasattr(utils, 'SamplerRange')\n"
+        "assert utils.lr_from_hr.__module__ == 'single-image-super-resolution_amd.utils'\n"
+        "assert model_generator.__name__ == 'single-image-super-resolution_amd.model_generator'\n"
+        "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), ROOT]))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd='/tmp')
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
 
 
 def test_fused_adam_is_a_torch_adam_with_the_same_defaults_and_state_layout():

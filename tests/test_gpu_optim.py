@@ -75,6 +75,32 @@ def test_fused_adam_state_dict_is_interchangeable_with_torch_adam():
         assert maxrel(p, q) < TOL
 
 
+def test_fused_adam_load_state_dict_with_static_gradient_tensors():
+    """step, load_state_dict, step again with the SAME .grad tensors (the HIP-graph replay situation: parameter and
+    gradient addresses never change): the loaded moments must be the ones the next step reads and writes"""
+    opt_mod = pkg('optim')
+    pa, pb = _params(3), _params(3)
+    oa, ob = opt_mod.Adam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3)
+    ga = [torch.full_like(p, 0.25) for p in pa]            # static gradient tensors, rewritten in place
+    for p, q, g in zip(pa, pb, ga):
+        p.grad, q.grad = g, g.clone()
+    oa.step(); ob.step()
+    donor = torch.optim.Adam(_params(4), lr=1e-3)          # a different optimizer history to load
+    for p in donor.param_groups[0]['params']:
+        p.grad = torch.rand(p.shape, generator=torch.Generator().manual_seed(5)).cuda()
+    donor.step(); donor.step()
+    sd = donor.state_dict()
+    oa.load_state_dict(sd); ob.load_state_dict(sd)
+    for g, q in zip(ga, pb):
+        g.fill_(-0.5)                                      # same tensors, new values
+        q.grad.fill_(-0.5)
+    oa.step(); ob.step()
+    for p, q in zip(pa, pb):
+        assert maxrel(p, q) < TOL
+        assert maxrel(oa.state[p]['exp_avg'], ob.state[q]['exp_avg']) < TOL
+        assert maxrel(oa.state[p]['exp_avg_sq'], ob.state[q]['exp_avg_sq']) < TOL
+
+
 def test_fused_adam_refuses_cpu_parameters():
     opt_mod = pkg('optim')
     p = torch.nn.Parameter(torch.zeros(4))
