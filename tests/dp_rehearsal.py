@@ -1,0 +1,92 @@
+"""Two data-parallel ranks of the HIP path sharing ONE GPU, exchanging gradients over gloo (RCCL refuses two
+ranks on one device; the exchange code is the same, only the backend differs).  Launched by
+tests/test_gpu_distributed.py through torch.distributed.run.  Each rank trains the same replica on a different
+shard of patches; checked: (1) the gradients the bucket-ready exchange leaves in .grad are the mean of the two
+ranks' local gradients, (2) after the optimizer step both ranks hold bit-identical parameters, (3) the same
+holds when the forward+backward is replayed from HIP-graph segments with the buckets reduced between segments."""
+import importlib
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = 'single-image-super-resolution_amd'
+sub = lambda n: importlib.import_module(PKG + '.' + n)     # noqa: E731
+
+
+def main():
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('gloo')
+    mg, ut, op, D, G = sub('model_generator'), sub('utils'), sub('optim'), sub('distributed'), sub('graph')
+    torch.manual_seed(0)
+    net = mg.Generator(8, 64, 256, [2], use_sn=True).to(dev).train()          # 8 blocks: tail + blocks4 + final buckets
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    hr = (torch.rand((2, 3, 32, 32), generator=torch.Generator().manual_seed(100 + rank)) * 2 - 1).to(dev)
+
+    def fwd_bwd():
+        lr = ut.lr_from_hr(hr, (16, 16), device=dev)
+        loss = 10.0 * torch.mean(torch.pow(hr - net(lr), 2))
+        net.zero_grad(set_to_none=True)
+        loss.backward()
+        return loss
+
+    # local gradients (no exchange) from the seed state, gathered from both ranks -> the expected mean
+    fwd_bwd()
+    local = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    want = {}
+    for k, g in local.items():
+        parts = [torch.empty_like(g) for _ in range(world)]
+        dist.all_gather(parts, g)
+        want[k] = sum(parts) / world
+    res = {}
+
+    def same_on_all_ranks():
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        lo, hi = flat.clone(), flat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return bool(torch.equal(lo, hi))
+
+    # ---- eager: buckets announced from inside the backward schedule ------------------------------------------
+    net.load_state_dict(state)
+    red = D.GradReducer(net, world)
+    opt = op.Adam(net.parameters(), lr=1e-4)
+    fwd_bwd()
+    red.finish()
+    res['eager_grad_err'] = max(float((p.grad - want[k]).abs().max()) / max(float(want[k].abs().max()), 1e-20)
+                                for k, p in net.named_parameters())
+    res['eager_stats'] = dict(red.stats)
+    opt.step()
+    fwd_bwd(); red.finish(); opt.step()
+    res['eager_params_identical'] = same_on_all_ranks()
+
+    # ---- HIP-graph segments with the reductions between them ---------------------------------------------------
+    net.load_state_dict(state)
+    red2 = D.GradReducer(net, world)
+    opt2 = op.Adam(net.parameters(), lr=1e-4)
+    red2.capture_mode(True)
+    step = G.GraphedStep(fwd_bwd, between=red2.launch_bucket)
+    red2.capture_mode(False)
+    net.load_state_dict(state)
+    res['graph_segments'] = len(step.graphs)
+    step(); red2.launch_remaining(); red2.finish()
+    res['graph_grad_err'] = max(float((p.grad - want[k]).abs().max()) / max(float(want[k].abs().max()), 1e-20)
+                                for k, p in net.named_parameters())
+    opt2.step()
+    step(); red2.launch_remaining(); red2.finish(); opt2.step()
+    res['graph_params_identical'] = same_on_all_ranks()
+    res['graph_stats'] = dict(red2.stats)
+    torch.cuda.synchronize()
+    if rank == 0:
+        print('DP_REHEARSAL ' + json.dumps(res), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -70,6 +70,44 @@ def run_case(name, module, cfg, in_shape, seed):
     print('%-28s out%s  %.2f MB' % (name, tuple(out.shape), os.path.getsize(path) / 1e6))
 
 
+def run_sampled_case(name, module, cfg, in_shape, seed):
+    """Full-depth networks: the state is NOT stored (it is regenerated from oracle/init.py's synth_state with
+    `state_seed`); big gradients are stored as a fixed strided sample of 4096 entries + their sum."""
+    torch.manual_seed(0)
+    state = load_synth(module, seed)
+    x = oinit.synth_input(in_shape, seed).requires_grad_(True)
+    module.train()
+    out = module(x)
+    r = oinit.synth_input(out.shape, seed + 1)
+    (out * r).sum().backward()
+    rec = {'cfg': np.array(json.dumps(dict(cfg, state_seed=seed))), 'x': x.detach().numpy(), 'r': r.numpy(),
+           'out': out.detach().numpy(), 'grad_x': x.grad.numpy()}
+    for k, p in module.named_parameters():
+        if p.numel() <= 4096:
+            rec['grad/' + k] = p.grad.numpy()
+        else:
+            flat = p.grad.reshape(-1)
+            rec['gradsample/' + k] = flat[:: max(1, flat.numel() // 4096)][:4096].numpy()
+            rec['gradsum/' + k] = np.array(flat.double().sum().item())
+    after = module.state_dict()
+    for k in after:
+        if k.endswith(('weight_u', 'weight_v', 'running_mean', 'running_var', 'num_batches_tracked')):
+            rec['after/' + k] = after[k].numpy().copy()
+    with torch.no_grad():
+        rec['out2'] = module(x).numpy()
+    del state
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **rec)
+    print('%-28s out%s  %.2f MB' % (name, tuple(out.shape), os.path.getsize(path) / 1e6))
+
+
+def deep_generator_cases():
+    """the benchmark's own architecture at full depth (16 residual blocks = 34 stacked conv+BatchNorm layers,
+    spectral norm everywhere; config.py:79-80) on a small batch"""
+    cfg = dict(kind='generator', n_blocks=16, nf=64, nl=256, list_scales=[2], use_sn=True, n_suffix=0)
+    run_sampled_case('gen_x2_sn_16blocks', ref_g.Generator(16, 64, 256, [2], use_sn=True), cfg, (2, 3, 16, 16), 14)
+
+
 def generator_cases():
     cfg = dict(kind='generator', n_blocks=1, nf=64, nl=256, list_scales=[2], use_sn=True, n_suffix=0)
     run_case('gen_x2_sn_w64', ref_g.Generator(1, 64, 256, [2], use_sn=True), cfg, (2, 3, 12, 12), 1)
@@ -197,7 +235,11 @@ def vgg_cases():
 
 if __name__ == '__main__':
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'deep':      # only the full-depth fixtures
+        deep_generator_cases()
+        sys.exit(0)
     generator_cases()
+    deep_generator_cases()
     progressive_cases()
     discriminator_cases()
     bicubic_cases()

@@ -69,3 +69,26 @@ def grads_close(got, ref, tol, floor=0.02):
         if not err < tol:
             bad.append((k, err))
     return bad
+
+
+def load_sampled_case(name, shapes):
+    """fixtures of full-depth networks: the state is regenerated from oracle/init.py (`state_seed`), big gradients
+    are stored as a strided sample of 4096 entries.  shapes: {state_dict key: shape} of the architecture.
+    -> z, cfg, state, sample(fn) where sample(grads) -> (got, ref) dicts restricted / strided like the fixture."""
+    from oracle import init as oinit
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    cfg = json.loads(str(z['cfg']))
+    state = oinit.synth_state(shapes, cfg['state_seed'])
+    after = {k[len('after/'):]: torch.from_numpy(z[k]) for k in z.files if k.startswith('after/')}
+
+    def sample(pg):
+        ref, got = {}, {}
+        for k in z.files:
+            if k.startswith('grad/'):
+                ref[k[5:]], got[k[5:]] = torch.from_numpy(z[k]), pg[k[5:]]
+            if k.startswith('gradsample/'):
+                flat = pg[k[11:]].reshape(-1)
+                ref[k[11:]] = torch.from_numpy(z[k])
+                got[k[11:]] = flat[:: max(1, flat.numel() // 4096)][:4096]
+        return got, ref
+    return z, cfg, state, after, sample

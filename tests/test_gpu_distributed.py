@@ -1,0 +1,25 @@
+"""GPU: two data-parallel ranks of the real modules on one GPU (gloo): see tests/dp_rehearsal.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_end_a_step_with_identical_parameters():
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['OMP_NUM_THREADS'] = '4'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29731', os.path.join(ROOT, 'tests', 'dp_rehearsal.py')],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith('DP_REHEARSAL ')][-1]
+    res = json.loads(line[len('DP_REHEARSAL '):])
+    assert res['eager_grad_err'] < 1e-6 and res['graph_grad_err'] < 1e-6, res
+    assert res['eager_params_identical'] and res['graph_params_identical'], res
+    assert res['eager_stats']['early_buckets'] == 6 and res['eager_stats']['late_buckets'] == 0, res      # 3 buckets x 2 steps
+    assert res['graph_segments'] == 4, res                     # tail | blocks4 | final | autograd hand-over

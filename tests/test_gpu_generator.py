@@ -50,6 +50,33 @@ def test_generator_matches_reference_golden(name):
         assert rel_err(net(x).cpu(), z['out_eval']) < TOL      # running statistics, no power iteration
 
 
+def test_full_depth_generator_matches_reference_golden():
+    """16 residual blocks (34 stacked conv+BatchNorm layers, spectral norm on every conv; the benchmark's own
+    architecture, config.py:79-80) at B2, LR 16: out / grad_x / sampled parameter gradients / advanced SN+BN state /
+    second training forward against vectors captured from the imported reference module, 1e-3 relative fp32"""
+    import json, os
+    import numpy as np
+    from helpers import GOLDEN, load_sampled_case
+    from test_oracle_golden import generator_shapes
+    cfg0 = json.loads(str(np.load(os.path.join(GOLDEN, 'gen_x2_sn_16blocks.npz'))['cfg']))
+    z, cfg, state, after, sample = load_sampled_case('gen_x2_sn_16blocks', generator_shapes(cfg0))
+    net = build(cfg)
+    net.load_state_dict(state, strict=True)
+    net = net.cuda().train()
+    x = torch.from_numpy(z['x']).cuda().requires_grad_(True)
+    out = net(x)
+    assert rel_err(out.detach().cpu(), z['out']) < TOL
+    (out * torch.from_numpy(z['r']).cuda()).sum().backward()
+    assert rel_err(x.grad.cpu(), z['grad_x']) < TOL
+    got, ref = sample({k: p.grad.detach().cpu() for k, p in net.named_parameters()})
+    assert grads_close(got, ref, TOL) == []
+    sd = net.state_dict()
+    for k, v in after.items():
+        assert rel_err(sd[k].cpu().double(), v.double()) < TOL, k
+    with torch.no_grad():
+        assert rel_err(net(x).cpu(), z['out2']) < TOL
+
+
 def test_no_silent_cpu_path():
     mg = pkg('model_generator')
     g = mg.Generator(1, 16, 64, [2])
