@@ -12,6 +12,9 @@ invalidated (a host synchronisation inside `fn`, an allocation the pool cannot s
 is synchronised, the HIP runtime's pending error is cleared and ``GraphCaptureError`` is raised with the reason, so
 the caller can decide to run eagerly (bench.py does, and says so in its output) instead of dying on the next launch.
 """
+import gc
+import threading
+
 import torch
 
 from . import _lib as L
@@ -22,6 +25,47 @@ class GraphCaptureError(RuntimeError):
 
 
 _ACTIVE = None          # the GraphedStep being captured (segment_boundary() talks to it)
+_CAPTURE_STREAM = {}    # device index -> THE capture stream of this process
+
+
+def _capture_stream(dev):
+    """One capture stream per device for every GraphedStep of the process (as torch.cuda.graph does).  Autograd
+    runs a parameter's AccumulateGrad node on the stream the node was created on, and nodes stay alive across
+    captures (any retained loss tensor holds them): with a stream per capture, the second graph of an iteration
+    (the G step after the D step: both accumulate into the discriminator's gradients) forks onto the first one's
+    capture stream and the graph gets a cross-stream branch -- measured on ROCm 7.2: its replay faults
+    (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in the first kernel behind the fork).  One stream = no forks: every
+    captured graph is a single chain."""
+    if dev not in _CAPTURE_STREAM:
+        _CAPTURE_STREAM[dev] = torch.cuda.Stream(device=dev)
+    return _CAPTURE_STREAM[dev]
+
+
+_TRIGGER = {}           # device -> (leaf tensor, its gradient seed) for _Call
+
+
+class _Call(torch.autograd.Function):
+    """identity whose backward calls a host function: a way to run that function on autograd's device thread"""
+
+    @staticmethod
+    def forward(ctx, x, fn):
+        ctx.fn = fn
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.fn()
+        return None, None
+
+
+def _detach(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach()
+    if isinstance(x, (tuple, list)):
+        return type(x)(_detach(v) for v in x)
+    if isinstance(x, dict):
+        return {k: _detach(v) for k, v in x.items()}
+    return x
 
 
 def segment_boundary(tag=None):
@@ -46,7 +90,15 @@ class GraphedStep:
     def __init__(self, fn, warmup=2, between=None):
         global _ACTIVE
         self.between = between
-        dev = torch.cuda.current_device()
+        # A segment boundary inside a backward pass is reached on autograd's device worker thread, and HIP (ROCm 7.2)
+        # only lets the thread that began a capture end it (hipErrorStreamCaptureWrongThread, also in relaxed mode).
+        # Segmented captures therefore issue EVERY capture begin / end on that worker thread (_on_worker); plain
+        # captures begin and end on the calling thread.
+        self._via_worker = between is not None
+        self._tid = None
+        dev = self._dev = torch.cuda.current_device()
+        if self._via_worker and dev not in _TRIGGER:
+            _TRIGGER[dev] = (torch.zeros(1, device='cuda:%d' % dev, requires_grad=True), torch.ones(1, device='cuda:%d' % dev))
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -54,19 +106,21 @@ class GraphedStep:
                 fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        gc.collect()                       # no tensor of the warm-up runs may be freed in the middle of the capture
+        torch.cuda.empty_cache()
         self.graphs, self.tags = [], []
         self._pool = torch.cuda.graph_pool_handle()
-        self._stream = torch.cuda.Stream(device=dev)
+        self._stream = _capture_stream(dev)
         self._stream.wait_stream(torch.cuda.current_stream())
         _ACTIVE = self
         try:
             with torch.cuda.stream(self._stream):
-                self._begin()
+                self._on_worker(self._begin)
                 try:
-                    self.out = fn()
-                    self._end()
+                    self.out = _detach(fn())     # static result tensors; the autograd graph behind them is dropped
+                    self._on_worker(self._end)
                 except BaseException:
-                    self._abandon()
+                    self._on_worker(self._abandon)
                     raise
         except Exception as e:                                   # noqa: BLE001
             _ACTIVE = None
@@ -77,6 +131,19 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(self._stream)
 
     # ---- capture plumbing --------------------------------------------------------------------------------
+    def _on_worker(self, f):
+        """run f() on autograd's worker thread of this device (segmented captures), else right here"""
+        if not self._via_worker or threading.get_ident() == self._tid:
+            return f()
+        x, g = _TRIGGER[self._dev]
+
+        def on_thread():
+            self._tid = threading.get_ident()
+            f()
+        # a backward pass whose only node is _Call: autograd executes the node on the device's worker thread, under
+        # the stream that is current here (the capture stream); no kernel is launched by the pass itself
+        torch.autograd.backward(_Call.apply(x, on_thread), g)
+
     def _begin(self):
         g = torch.cuda.CUDAGraph()
         g.capture_begin(pool=self._pool)
@@ -86,9 +153,11 @@ class GraphedStep:
         self.graphs[-1].capture_end()
 
     def _next_segment(self, tag):
-        self._end()
-        self.tags.append(tag)
-        self._begin()
+        def cut():
+            self._end()
+            self.tags.append(tag)
+            self._begin()
+        self._on_worker(cut)
 
     def _abandon(self):
         try:

@@ -1,6 +1,8 @@
 """GPU: the fused multi-tensor Adam against torch.optim.Adam -- the optimizer the reference
 instantiates (config.py:292-294) -- and against the oracle restatement, over several steps with the reference's
 LambdaLR decay (config.py:170-180).  Tolerance 1e-6 relative per tensor (same fp32 formula, different fma grouping)."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -90,7 +92,8 @@ def test_fused_adam_load_state_dict_with_static_gradient_tensors():
         p.grad = torch.rand(p.shape, generator=torch.Generator().manual_seed(5)).cuda()
     donor.step(); donor.step()
     sd = donor.state_dict()
-    oa.load_state_dict(sd); ob.load_state_dict(sd)
+    # (torch hands the SAME 'step' tensor object to every optimizer that loads one state_dict: load copies)
+    oa.load_state_dict(copy.deepcopy(sd)); ob.load_state_dict(copy.deepcopy(sd))
     for g, q in zip(ga, pb):
         g.fill_(-0.5)                                      # same tensors, new values
         q.grad.fill_(-0.5)
