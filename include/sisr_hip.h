@@ -95,6 +95,10 @@ typedef struct SisrConvDesc {
     int32_t y_sy, y_oy, y_sx, y_ox, y_H, y_W; /* output pixel (oy*y_sy+y_oy, ox*y_sx+y_ox) of a
                                                 y_H x y_W image (strided scatter for the data
                                                 gradient of stride-2 convs); plain: 1,0,1,0,Ho,Wo */
+    /* storage type of the tensors behind the float* fields (0: fp32, 1: bf16 -- the bf16 build keeps NHWC
+     * activations and gradients as bf16 in HBM; all arithmetic, accumulation and statistics stay fp32).
+     * x_bf16: x1 and x2;  y_bf16: y (NHWC / NHWC_SHUFFLE2 only);  res_bf16: res;  bnbx_bf16: bnb_x. */
+    int32_t x_bf16, y_bf16, res_bf16, bnbx_bf16;
     SisrConvPlan plan;
 } SisrConvDesc;
 
@@ -125,6 +129,7 @@ typedef struct SisrWgradDesc {
     int32_t NJ, NP, NT, TSTEP, TVALID;       /* co sub-tiles, pixel parts, row tiles          */
     int32_t grid_x, n_slabs, slab_elems, lds_bytes;
     uint32_t m_tiles_x, m_tiles_y, m_iw, m_twp, m_kw;   /* bf16 kernel: reciprocals as in SisrConvPlan */
+    int32_t x_bf16, g_bf16;                  /* storage type of x1/x2 and of g1/g2 (0: fp32, 1: bf16) */
     int32_t pad_;
     int64_t slab_stride;                     /* set by the caller after planning              */
 } SisrWgradDesc;
@@ -227,6 +232,7 @@ typedef struct SisrBnBwdDesc {
     int32_t act_mode;
     const float *slope_p; float slope;     /* device scalar slope, or NULL: use `slope`       */
     int32_t grid;                          /* filled by sisr_bn_bwd_plan                      */
+    int32_t dy_bf16, x_bf16;               /* storage type of dy and x (0: fp32, 1: bf16)     */
 } SisrBnBwdDesc;
 int sisr_bn_bwd_plan(SisrBnBwdDesc *d);
 int sisr_bn_bwd(const SisrBnBwdDesc *d, void *stream);
@@ -236,15 +242,18 @@ int sisr_bn_bwd_finalize(const SisrBnBwdDesc *d, void *stream);
 /* elementwise: y = f(x1) + (pa ? pa[c]*x2 + pd[c] : x2)   over NHWC [P][C];
  * f = lrelu(., slope1_p ? *slope1_p : slope1) -- the residual add of BasicBlock.forward (model_generator.py:19) and the
  * long skip (model_generator.py:93) with the BatchNorm apply fused.  x2 may be NULL (y = f(x1)). */
+/* Elementwise entry points take a storage word `dt`: bit k set = the k-th tensor argument (in argument order,
+ * inputs then output) is bf16 instead of fp32 (SISR_DT(a, b, c) below); arithmetic is fp32 either way. */
+#define SISR_DT(a, b, c) ((a) | ((b) << 1) | ((c) << 2))
 int sisr_eltwise_res_affine(const float *x1, const float *slope1_p, float slope1, const float *x2,
-                            const float *pa, const float *pd, float *y, int64_t P, int32_t C,
+                            const float *pa, const float *pd, float *y, int64_t P, int32_t C, int32_t dt /* x1, x2, y */,
                             void *stream);
 /* sum over all elements where pre<=0 of dy*pre  -> out[0]  (gradient of a PReLU slope that is
  * not followed by... BatchNorm-free sites: model_generator.py:34,48) ; work: [grid] floats */
 int sisr_prelu_slope_grad(const float *dy, const float *pre, int64_t n, float *work, float *out,
-                          void *stream);
+                          int32_t dt /* dy, pre */, void *stream);
 /* y = a + b (same shape) */
-int sisr_add(const float *a, const float *b, float *y, int64_t n, void *stream);
+int sisr_add(const float *a, const float *b, float *y, int64_t n, int32_t dt /* a, b, y */, void *stream);
 
 /* ---- layout materialisation ------------------------------------------------------------------
  * NHWC [N][H][W][C] -> NCHW destination with row stride `dst_stride` floats per image (so a feature
@@ -253,11 +262,11 @@ int sisr_add(const float *a, const float *b, float *y, int64_t n, void *stream);
  * MaskedVGG's taps (model_content_extractor.py:57-60) and forward_no_end (model_generator.py:86). */
 int sisr_nhwc_to_nchw(const float *x, const float *pa, const float *pd, const float *slope_p,
                       float slope, float *y, int64_t dst_stride, int32_t N, int32_t H, int32_t W,
-                      int32_t C, void *stream);
+                      int32_t C, int32_t x_bf16, void *stream);
 /* inverse gather: NCHW source (row stride src_stride per image) -> NHWC, y = x * (mask_pre ?
  * (lrelu'(mask_pre)) : 1) is NOT applied here: plain layout change. */
 int sisr_nchw_to_nhwc(const float *x, int64_t src_stride, float *y, int32_t N, int32_t H, int32_t W,
-                      int32_t C, void *stream);
+                      int32_t C, int32_t y_bf16, void *stream);
 /* NCHW gradient (C <= Cpad channels) -> NHWC [N][H][W][Cpad] with zero padding channels; out != NULL fuses the
  * tanh backward g = dy*(1 - out^2) of the generator's last layer (model_generator.py:54, nn.Tanh after the
  * final conv).  Feeds the bf16 weight gradient of that 3-channel conv. */
@@ -269,13 +278,14 @@ int sisr_nchw_grad_to_nhwc4(const float *dy, const float *out, float *g, int32_t
  * output and the consumer applies ReLU lazily; the backward fuses MaxPool' and ReLU':
  *   dx[argmax of the 2x2 window] = (x[argmax] > 0) ? dy : 0, all other positions 0
  * (first maximum in row-major window order, like ATen). */
-int sisr_maxpool2_fwd(const float *x, float *y, int32_t N, int32_t H, int32_t W, int32_t C, void *stream);
+int sisr_maxpool2_fwd(const float *x, float *y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dt /* x, y */,
+                      void *stream);
 int sisr_maxpool2_relu_bwd(const float *dy, const float *x, float *dx, int32_t N, int32_t H, int32_t W,
-                           int32_t C, void *stream);
+                           int32_t C, int32_t dt /* dy, x, dx */, void *stream);
 /* out = a + (ref > 0 ? b : 0)   (a may be NULL: out = masked b) -- merges a tap gradient into the
  * gradient of the ReLU it was taken behind (MaskedVGG's in-place-ReLU aliasing). */
 int sisr_add_relu_masked(const float *a, const float *b, const float *ref, float *out, int64_t n,
-                         void *stream);
+                         int32_t dt /* a, b, ref, out */, void *stream);
 
 /* ---- fully connected layers of D (nn.Linear, model_discriminator.py:47-53); weight-streaming,
  *      HBM-bound on W[Nout][K] (75-302 MB).  x operand: lrelu(x, in_slope) applied on load. ------ */

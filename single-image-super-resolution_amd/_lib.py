@@ -39,6 +39,7 @@ class ConvDesc(C.Structure):
                 [('pro_slope_p', _f), ('pro_slope', _f32)] +
                 [('y_mode', _i32), ('epi_act', _i32), ('bnb_act', _i32), ('bnb_slope', _f32)] +
                 [(n, _i32) for n in ('y_sy', 'y_oy', 'y_sx', 'y_ox', 'y_H', 'y_W')] +
+                [(n, _i32) for n in ('x_bf16', 'y_bf16', 'res_bf16', 'bnbx_bf16')] +
                 [('plan', ConvPlan)])
 
 
@@ -53,7 +54,8 @@ class WgradDesc(C.Structure):
                                      'CK', 'PS', 'KROWP', 'n_chunk', 'CoutPad',
                                      'NJ', 'NP', 'NT', 'TSTEP', 'TVALID',
                                      'grid_x', 'n_slabs', 'slab_elems', 'lds_bytes')] +
-                [(n, C.c_uint32) for n in ('m_tiles_x', 'm_tiles_y', 'm_iw', 'm_twp', 'm_kw')] + [('pad_', _i32)] +
+                [(n, C.c_uint32) for n in ('m_tiles_x', 'm_tiles_y', 'm_iw', 'm_twp', 'm_kw')] +
+                [('x_bf16', _i32), ('g_bf16', _i32), ('pad_', _i32)] +
                 [('slab_stride', _i64)])
 
 
@@ -84,7 +86,7 @@ class BnBwdDesc(C.Structure):
     _fields_ = ([(n, _f) for n in ('dy', 'x', 'scale', 'shift', 'mean', 'invstd', 'gamma', 'work',
                                    'qa', 'qb', 'qd', 'dgamma', 'dbeta', 'dslope')] +
                 [('P', _i64), ('C', _i32), ('act_mode', _i32), ('slope_p', _f), ('slope', _f32),
-                 ('grid', _i32)])
+                 ('grid', _i32), ('dy_bf16', _i32), ('x_bf16', _i32)])
 
 
 _SIGS = {
@@ -105,17 +107,17 @@ _SIGS = {
     'sisr_bn_bwd_plan': [C.POINTER(BnBwdDesc)],
     'sisr_bn_bwd': [C.POINTER(BnBwdDesc), _f],
     'sisr_bn_bwd_finalize': [C.POINTER(BnBwdDesc), _f],
-    'sisr_eltwise_res_affine': [_f, _f, _f32, _f, _f, _f, _f, _i64, _i32, _f],
-    'sisr_prelu_slope_grad': [_f, _f, _i64, _f, _f, _f],
-    'sisr_add': [_f, _f, _f, _i64, _f],
+    'sisr_eltwise_res_affine': [_f, _f, _f32, _f, _f, _f, _f, _i64, _i32, _i32, _f],
+    'sisr_prelu_slope_grad': [_f, _f, _i64, _f, _f, _i32, _f],
+    'sisr_add': [_f, _f, _f, _i64, _i32, _f],
     'sisr_adam_blocks': [_i64],
     'sisr_adam_step': [_f, _i32, _i64] + [C.c_double] * 7 + [_f],
-    'sisr_nhwc_to_nchw': [_f, _f, _f, _f, _f32, _f, _i64, _i32, _i32, _i32, _i32, _f],
-    'sisr_nchw_to_nhwc': [_f, _i64, _f, _i32, _i32, _i32, _i32, _f],
+    'sisr_nhwc_to_nchw': [_f, _f, _f, _f, _f32, _f, _i64, _i32, _i32, _i32, _i32, _i32, _f],
+    'sisr_nchw_to_nhwc': [_f, _i64, _f, _i32, _i32, _i32, _i32, _i32, _f],
     'sisr_nchw_grad_to_nhwc4': [_f, _f, _f, _i32, _i32, _i32, _i32, _i32, _f],
-    'sisr_maxpool2_fwd': [_f, _f, _i32, _i32, _i32, _i32, _f],
-    'sisr_maxpool2_relu_bwd': [_f, _f, _f, _i32, _i32, _i32, _i32, _f],
-    'sisr_add_relu_masked': [_f, _f, _f, _f, _i64, _f],
+    'sisr_maxpool2_fwd': [_f, _f, _i32, _i32, _i32, _i32, _i32, _f],
+    'sisr_maxpool2_relu_bwd': [_f, _f, _f, _i32, _i32, _i32, _i32, _i32, _f],
+    'sisr_add_relu_masked': [_f, _f, _f, _f, _i64, _i32, _f],
     'sisr_fc_forward': [_f, _f32, _f, _f, _f, _i32, _i32, _i32, _i32, _f],
     'sisr_fc_dgrad_splits': [_i32, _i32],
     'sisr_fc_dgrad': [_f, _f, _f, _f, _i32, _i32, _i32, _f],

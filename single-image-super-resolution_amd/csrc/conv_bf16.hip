@@ -76,7 +76,9 @@ __device__ __forceinline__ void conv_bf16_tap(const __bf16* const (&ap)[MSUB], c
     __builtin_amdgcn_sched_group_barrier(0x008, 2 * MSUB * NSUB, 0);
 }
 
-template <int MSUB, int NSUB, int TAG>
+// XBF / YBF: storage type of the input operand (x1, x2) and of the output side (y, res, bnb_x): compile-time so that
+// each instantiation carries one staging family and one epilogue (registers: 3 waves per SIMD for the 128-pixel tiles)
+template <int MSUB, int NSUB, int TAG, bool XBF, bool YBF>
 __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const SisrConvDesc d) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const SisrConvPlan& p = d.plan;
@@ -178,6 +180,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
     ov.N = d.N; ov.H = d.H; ov.W = d.W; ov.C = d.Cin;
     ov.mode = d.x_mode; ov.pro = d.pro_mode;
     ov.slope = d.pro_slope_p ? d.pro_slope_p[0] : d.pro_slope;
+    ov.bf16 = d.x_bf16;
     const int iy_org = oy0 * S - d.pad_y, ix_org = ox0 * S - d.pad_x;
     const int wstep_j = fdiv(SISR_BLOCK, p.m_wrow), wstep_k = SISR_BLOCK - wstep_j * wvec_row;
     const int wstep_off = wstep_j * WS + wstep_k * 8;
@@ -186,7 +189,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
     for (int chunk = 0; chunk < p.n_chunk; ++chunk) {
         __syncthreads();   // all fragment reads of the previous chunk are done
         TR(1 + 4 * (chunk & 1));
-        stage_operand_tile_bf16(ov, lds_in, BF_PS, BF_CK, chunk * BF_CK, p.TN, IH, IW, n0, iy_org, ix_org, 1 << 30, p.m_iw);
+        stage_operand_tile_bf16<8, XBF ? 1 : 0>(ov, lds_in, BF_PS, BF_CK, chunk * BF_CK, p.TN, IH, IW, n0, iy_org, ix_org, 1 << 30, p.m_iw);
         TR(2 + 4 * (chunk & 1));
         {   // this chunk's packed weights are already in registers (loaded during the previous MFMA phase / the
             // kernel prologue): write them to LDS, then put the next chunk's loads in flight
@@ -303,8 +306,144 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
     }
     TR(11);
 
+    const unsigned ypix = (unsigned)max(d.N * d.y_H * d.y_W, d.N * d.Ho * d.Wo);
+    if constexpr (YBF) {
+        // ---- bf16 tensors in HBM (NHWC / pixel-shuffled NHWC output): every global access of the epilogue is a
+        // 16-byte access of 8 consecutive channels of one pixel; the change between that layout and the accumulator
+        // layout (lane = channel, registers = pixels) goes through LDS with the transposing read ds_read_b64_tr_b16:
+        //   residual / BatchNorm input: global -> [pixel][RS] image -> transposed read = 4 consecutive pixels of the
+        //   lane's channel = one accumulator register group;  output: 4 pixels of a register group packed (8 bytes)
+        //   -> [channel][YS] image -> transposed read = 4 consecutive channels of one pixel, two reads = 16 bytes.
+        constexpr int RS = BN + 8, YS = BM + 4, OCT = BN / 8;
+        __bf16* img_r = lds_in;
+        __bf16* img_x = lds_in + BM * RS;
+        __bf16* img_y = reinterpret_cast<__bf16*>(red + 12 * BN);
+        const unsigned ybytes2 = ypix * (unsigned)d.Cout * 2u;
+        const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+        const bool has_r = d.res != nullptr, has_x = d.bnb_part != nullptr;
+        s16x4 pr[MSUB][NSUB][4], px[MSUB][NSUB][4];
+        if (has_r || has_x) {
+            const __amdgpu_buffer_rsrc_t rr = bf_rsrc(has_r ? d.res : d.bnb_x, ybytes2);
+            const __amdgpu_buffer_rsrc_t rx = bf_rsrc(has_x ? d.bnb_x : d.res, ybytes2);
+            constexpr int ITEMS = BM * OCT / SISR_BLOCK;           // 16-byte items per thread and tensor
+            u32x4 vr[ITEMS], vx[ITEMS];
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                const int idx = tid + k * SISR_BLOCK, m = idx / OCT, oc = idx - m * OCT;
+                const int ro = row_off[m], ch = cout_base + oc * 8;
+                const unsigned vo = (ro >= 0 && ch < d.Cout) ? (unsigned)(ro + ch) * 2u : 0x80000000u;
+                if (has_r) vr[k] = __builtin_amdgcn_raw_buffer_load_b128(rr, vo, 0, 0);
+                if (has_x) vx[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                const int idx = tid + k * SISR_BLOCK, m = idx / OCT, oc = idx - m * OCT;
+                if (has_r) *reinterpret_cast<u32x4*>(img_r + m * RS + oc * 8) = vr[k];
+                if (has_x) *reinterpret_cast<u32x4*>(img_x + m * RS + oc * 8) = vx[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        // this 16-lane group's block: pixels 8g + 4kk .. +3 (rows), channels 16 * (l31 >> 4) .. +15
+                        const int off = (wave * (MSUB * 32) + ms * 32 + 8 * g + 4 * (grp >> 1) + tq) * RS + ns * 32 + 16 * (grp & 1) + 4 * tp;
+                        if (has_r) pr[ms][ns][g] = lds_tr16(img_r + off);
+                        if (has_x) px[ms][ns][g] = lds_tr16(img_x + off);
+                    }
+        }
+        if (has_r) {
+#pragma unroll
+            for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        acc[ms][ns][i] += bf16_bits_to_f32((unsigned short)pr[ms][ns][i >> 2][i & 3]);
+        }
+        if (has_x) {
+            // BatchNorm-backward reductions of the gradient tile just formed (see the fp32-storage branch below)
+            const float bslope = d.bnb_slope_p ? d.bnb_slope_p[0] : d.bnb_slope;
+            float ssl = 0.f;
+            __syncthreads();                               // the images are consumed; `red` is free
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns) {
+                const int cp = cout_base + ns * 32 + l31;
+                float sc = 0.f, sf = 0.f, mu = 0.f, is = 0.f;
+                if (col_ok[ns]) { sc = d.bnb_scale[cp]; sf = d.bnb_shift[cp]; mu = d.bnb_mean[cp]; is = d.bnb_invstd[cp]; }
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float xv = bf16_bits_to_f32((unsigned short)px[ms][ns][i >> 2][i & 3]);
+                        float g = rv[ms][i] ? (float)acc[ms][ns][i] : 0.f;
+                        if (d.bnb_act) {
+                            const float z = sc * xv + sf;
+                            if (!(z > 0.f)) { ssl += g * z; g *= bslope; }
+                        }
+                        s1 += g;
+                        s2 += g * ((xv - mu) * is);
+                    }
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (kk == 0) { red[(wave * BN + ns * 32 + l31) * 2] = s1; red[(wave * BN + ns * 32 + l31) * 2 + 1] = s2; }
+            }
+            ssl = wave_sum(ssl);
+            if (lane == 0) red[8 * BN + wave] = ssl;
+            __syncthreads();
+            float* wk = d.bnb_part + (int64_t)tile_id * (2 * d.Cout + 1);
+            if (tid < BN && cout_base + tid < d.Cout) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { s1 += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
+                wk[cout_base + tid] = s1;
+                wk[d.Cout + cout_base + tid] = s2;
+            }
+            if (tid == 0 && blockIdx.z == 0) wk[2 * d.Cout] = red[8 * BN] + red[8 * BN + 1] + red[8 * BN + 2] + red[8 * BN + 3];
+        } else if (has_r) {
+            __syncthreads();                               // img_y may overlap the residual image
+        }
+        // output: accumulators -> bf16 -> [channel][YS] image (this wave's pixel columns only: no barrier needed)
+#pragma unroll
+        for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float v = acc[ms][ns][4 * g + j]; h[j] = (__bf16)v; }
+                    *reinterpret_cast<bf16x4*>(img_y + (ns * 32 + l31) * YS + wave * (MSUB * 32) + ms * 32 + 8 * g + 4 * kk) = h;
+                }
+        const __amdgpu_buffer_rsrc_t ry = bf_rsrc(d.y, ybytes2);
+        const int Cq = d.Cout >> 2;
+        // pass: the two 16-lane groups of a wave half take two 16-pixel blocks, the halves take two channel octets
+#pragma unroll
+        for (int ps = 0; ps < MSUB * OCT / 2; ++ps) {
+            const int pb = 2 * (ps / (OCT / 2)) + (grp & 1);              // 16-pixel block of this wave's rows
+            const int oc = 2 * (ps % (OCT / 2)) + (grp >> 1);              // channel octet
+            const int m0 = wave * (MSUB * 32) + 16 * pb;
+            const __bf16* src = img_y + (oc * 8 + tq) * YS + m0 + 4 * tp;
+            const s16x4 lo = lds_tr16(src), hi = lds_tr16(src + 4 * YS);
+            const int ro = row_off[m0 + (lane & 15)];
+            const int cp = cout_base + oc * 8;
+            int choff = cp;
+            if (d.y_mode == SISR_Y_NHWC_SHUFFLE2) {
+                const int ij = cp / Cq, c = cp - ij * Cq;
+                choff = ((ij >> 1) * (2 * d.Wo) + (ij & 1)) * Cq + c;
+            }
+            const unsigned vo = (ro >= 0 && cp < d.Cout) ? (unsigned)(ro + choff) * 2u : 0x80000000u;
+            const s16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v8), ry, vo, 0, 0);
+        }
+        TR(12);
+        return;
+    } else {
     // output (and residual) through raw buffer accesses with 32-bit byte offsets
-    const unsigned ybytes = (unsigned)max(d.N * d.y_H * d.y_W, d.N * d.Ho * d.Wo) * (unsigned)d.Cout * 4u;
+    const unsigned ybytes = ypix * (unsigned)d.Cout * 4u;
     const __amdgpu_buffer_rsrc_t ry = bf_rsrc(d.y, ybytes);
     // fused BatchNorm-backward reductions (below): that BatchNorm's input at this lane's pixels, requested before
     // the residual so both sets of loads share one memory latency
@@ -396,6 +535,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) conv_mfma_bf16_kernel(const Sis
                 }
         }
     TR(12);
+    }
 }
 
 // ---- host ------------------------------------------------------------------------------------------
@@ -404,8 +544,11 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static int conv_bf16_lds_bytes(int BM, int TN, int TH, int TW, int S, int KH, int KW, int BN) {
     const int IH = (TH - 1) * S + KH, IW = (TW - 1) * S + KW;
     const int in_elems = (TN * IH * IW * BF_PS + 16 + 7) & ~7;
-    const int w_bytes = std::max(BN * (KH * KW * BF_CK + 8) * 2, 12 * BN * 4);       // weights / statistics scratch
-    return BM * 4 + in_elems * 2 + w_bytes + 16;
+    // weights, later the epilogue's reduction scratch (12*BN floats) followed by the [BN][BM+4] bf16 output image
+    const int w_bytes = std::max(BN * (KH * KW * BF_CK + 8) * 2, 12 * BN * 4 + BN * (BM + 4) * 2);
+    // bf16 residual / BatchNorm-input images [BM][BN+8] x 2 start at the input tile
+    const int img_bytes = 2 * BM * (BN + 8) * 2;
+    return BM * 4 + std::max(in_elems * 2 + w_bytes, img_bytes) + 16;
 }
 
 extern "C" int sisr_conv2d_plan_bf16(SisrConvDesc* d) {
@@ -476,25 +619,40 @@ extern "C" int sisr_conv2d_plan_bf16(SisrConvDesc* d) {
     return 0;
 }
 
-template <int MSUB, int NSUB, int TAG>
-static int launch_conv_bf16(const SisrConvDesc* d, hipStream_t st) {
+// (lds_max: one process drives one GPU from one thread -- the design of this path; a multi-device / multi-thread
+// host would need this per device)
+template <int MSUB, int NSUB, int TAG, bool XBF, bool YBF>
+static int launch_conv_bf16_t(const SisrConvDesc* d, hipStream_t st) {
     static int lds_max = 64 * 1024;
     if (d->plan.lds_bytes > lds_max) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16_kernel<MSUB, NSUB, TAG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16_kernel<MSUB, NSUB, TAG, XBF, YBF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, d->plan.lds_bytes);
         if (e != hipSuccess) return (int)e;
         lds_max = d->plan.lds_bytes;
     }
     const dim3 grid(d->plan.tiles_x * d->plan.tiles_y, d->plan.n_groups, d->plan.CoutPad / (NSUB * 32));
-    hipLaunchKernelGGL((conv_mfma_bf16_kernel<MSUB, NSUB, TAG>), grid, dim3(SISR_BLOCK), d->plan.lds_bytes, st, *d);
+    hipLaunchKernelGGL((conv_mfma_bf16_kernel<MSUB, NSUB, TAG, XBF, YBF>), grid, dim3(SISR_BLOCK), d->plan.lds_bytes, st, *d);
     SISR_CHECK_LAUNCH();
     return 0;
+}
+
+// storage combinations: all fp32 | bf16 in, bf16 out | bf16 in, fp32 out (NCHW images) | fp32 in, bf16 out (gradients
+// that enter the bf16 tensors from an fp32 producer)
+template <int MSUB, int NSUB, int TAG>
+static int launch_conv_bf16(const SisrConvDesc* d, hipStream_t st) {
+    if (d->x_bf16) return d->y_bf16 ? launch_conv_bf16_t<MSUB, NSUB, TAG, true, true>(d, st) : launch_conv_bf16_t<MSUB, NSUB, TAG, true, false>(d, st);
+    return d->y_bf16 ? launch_conv_bf16_t<MSUB, NSUB, TAG, false, true>(d, st) : launch_conv_bf16_t<MSUB, NSUB, TAG, false, false>(d, st);
 }
 
 extern "C" int sisr_conv2d_bf16(const SisrConvDesc* d, void* stream) {
     if (!d || !d->x1 || !d->wpk || !d->y) return SISR_E_BADARG;
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
     if (d->stat_part && (!d->cnt_part || d->y_mode != SISR_Y_NHWC)) return SISR_E_BADARG;
+    if (d->y_bf16 && (d->y_mode == SISR_Y_NCHW || (d->Cout & 7) || d->epi_act != SISR_EPI_NONE ||
+                      (d->y_mode == SISR_Y_NHWC_SHUFFLE2 && ((d->Cout >> 2) & 7)) || (d->res && !d->res_bf16) ||
+                      (d->bnb_part && !d->bnbx_bf16) || (d->res && d->y_mode != SISR_Y_NHWC)))
+        return SISR_E_UNSUPPORTED;
+    if (!d->y_bf16 && ((d->res && d->res_bf16) || (d->bnb_part && d->bnbx_bf16))) return SISR_E_UNSUPPORTED;
     if (d->bnb_part && (d->y_mode != SISR_Y_NHWC || d->y_sy != 1 || d->y_sx != 1 || d->y_H != d->Ho || d->y_W != d->Wo ||
                         !d->bnb_x || !d->bnb_scale || !d->bnb_shift || !d->bnb_mean || !d->bnb_invstd ||
                         d->epi_act != SISR_EPI_NONE || d->plan.CoutPad / (d->plan.nsub * 32) != 1))
@@ -510,8 +668,7 @@ extern "C" int sisr_conv2d_bf16(const SisrConvDesc* d, void* stream) {
     // roles (data gradients), 0 = everything else; profiles then report the roles separately
     const bool trunk = d->Cin == 64 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1;
     const int tag = !trunk ? 0 : (d->stat_part ? 1 : 2);
-    if (p.msub == 2 && p.nsub == 2)
-        return tag == 1 ? launch_conv_bf16<2, 2, 1>(d, st) : tag == 2 ? launch_conv_bf16<2, 2, 2>(d, st) : launch_conv_bf16<2, 2, 0>(d, st);
+    if (p.msub == 2 && p.nsub == 2) return launch_conv_bf16<2, 2, 0>(d, st);
     if (p.msub == 2 && p.nsub == 1) return launch_conv_bf16<2, 1, 0>(d, st);
     if (p.msub == 1 && p.nsub == 2)
         return tag == 1 ? launch_conv_bf16<1, 2, 1>(d, st) : tag == 2 ? launch_conv_bf16<1, 2, 2>(d, st) : launch_conv_bf16<1, 2, 0>(d, st);

@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, MSUB == 1 ? 3 : 2) conv_mfma_f32_k
     ov.N = d.N; ov.H = d.H; ov.W = d.W; ov.C = d.Cin;
     ov.mode = d.x_mode; ov.pro = d.pro_mode;
     ov.slope = d.pro_slope_p ? d.pro_slope_p[0] : d.pro_slope;
+    ov.bf16 = d.x_bf16;
     const bool vec_ok = (d.x_mode != SISR_X_NCHW) && !(p.CK & 3) && !((p.CK >> 2) & ((p.CK >> 2) - 1)) && !(d.Cin & 3) &&
                         !(d.x_mode == SISR_X_NHWC_UNSHUFFLE2 && ((d.Cin >> 2) & 3));
     const int iy_org = oy0 * S - d.pad_y, ix_org = ox0 * S - d.pad_x;
@@ -255,6 +256,24 @@ __global__ void __launch_bounds__(SISR_BLOCK, MSUB == 1 ? 3 : 2) conv_mfma_f32_k
             const int o = row_off[wave * (MSUB * 32) + ms * 32 + mfma_row(i, lane)];
             rb[ms][i] = o >= 0 ? (unsigned)o * 4u : 0x80000000u;
         }
+    if (d.y_bf16) {
+        // bf16 output tensor (edge layers of the bf16 build: the 3-channel convs keep the exact-fp32 contraction but
+        // hand a bf16 NHWC tensor to the bf16 kernels): 2-byte stores, no residual / tanh (checked by the launcher)
+        const unsigned yb2 = (unsigned)max(d.N * d.y_H * d.y_W, d.N * d.Ho * d.Wo) * (unsigned)d.Cout * 2u;
+        const __amdgpu_buffer_rsrc_t ry2 = sisr_rsrc(d.y, yb2);
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns)
+            if (col_ok[ns]) {
+#pragma unroll
+                for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float val = acc[ms][ns][i];
+                        __builtin_amdgcn_raw_buffer_store_b16((short)f32_to_bf16_bits(val), ry2, (rb[ms][i] >> 1) + (rb[ms][i] >> 31 ? 0x80000000u : 0u) + (unsigned)col_off[ns] * 2u, 0, 0);
+                    }
+            }
+        return;
+    }
     const unsigned ybytes = (unsigned)max(d.N * d.y_H * d.y_W, d.N * d.Ho * d.Wo) * (unsigned)d.Cout * 4u;
     if (d.res != nullptr) {
         const __amdgpu_buffer_rsrc_t rr = sisr_rsrc(d.res, ybytes);
@@ -404,6 +423,8 @@ extern "C" int sisr_conv2d_f32(const SisrConvDesc* d, void* stream) {
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
     if (d->stat_part && !d->cnt_part) return SISR_E_BADARG;
     if (d->stat_part && d->y_mode != SISR_Y_NHWC) return SISR_E_UNSUPPORTED;
+    if (d->y_bf16 && (d->y_mode == SISR_Y_NCHW || d->res || d->epi_act != SISR_EPI_NONE)) return SISR_E_UNSUPPORTED;
+    if (d->res && d->res_bf16) return SISR_E_UNSUPPORTED;
     const SisrConvPlan& p = d->plan;
     if (p.n_tiles <= 0 || p.lds_bytes <= 0 || p.lds_bytes > 160 * 1024) return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

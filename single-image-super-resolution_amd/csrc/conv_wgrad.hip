@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_f32_kernel(const Sis
     og.x1 = d.g1; og.x2 = d.g2; og.pa = d.qa; og.pb = d.qb; og.pd = d.qd; og.ps = d.qs; og.pt = d.qt;
     og.N = d.N; og.H = d.Ho; og.W = d.Wo; og.C = d.Cout; og.mode = d.g_mode; og.pro = d.gpro_mode;
     og.slope = d.gpro_slope_p ? d.gpro_slope_p[0] : d.gpro_slope;
+    ox.bf16 = d.x_bf16; og.bf16 = d.g_bf16;
     const bool xvec = (d.x_mode != SISR_X_NCHW) && !(d.CK & 3) && !((d.CK >> 2) & ((d.CK >> 2) - 1)) && !(d.Cin & 3) &&
                       !(d.x_mode == SISR_X_NHWC_UNSHUFFLE2 && ((d.Cin >> 2) & 3));
     const bool gvec = (d.g_mode != SISR_X_NCHW) && !(d.Cout & 3) &&

@@ -14,7 +14,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) nhwc_to_nchw_kernel(const float* _
                                                                   const float* __restrict__ pd,
                                                                   const float* slope_p, float slope,
                                                                   float* __restrict__ y, int64_t dst_stride,
-                                                                  int HW, int C) {
+                                                                  int HW, int C, int x_bf16) {
     __shared__ float tile[32][33];
     if (slope_p != nullptr) slope = slope_p[0];
     const int n = blockIdx.z;
@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) nhwc_to_nchw_kernel(const float* _
         const int p = p0 + i, c = c0 + tx;
         float v = 0.f;
         if (p < HW && c < C) {
-            v = x[((int64_t)n * HW + p) * C + c];
+            v = ld_elem(x, ((int64_t)n * HW + p) * C + c, x_bf16 != 0);
             if (pa != nullptr) v = pa[c] * v + pd[c];
             v = lrelu(v, slope);
         }
@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) nhwc_to_nchw_kernel(const float* _
 }
 
 __global__ void __launch_bounds__(SISR_BLOCK) nchw_to_nhwc_kernel(const float* __restrict__ x, int64_t src_stride,
-                                                                  float* __restrict__ y, int HW, int C) {
+                                                                  float* __restrict__ y, int HW, int C, int y_bf16) {
     __shared__ float tile[32][33];
     const int n = blockIdx.z;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) nchw_to_nhwc_kernel(const float* _
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int p = p0 + i, c = c0 + tx;
-        if (p < HW && c < C) y[((int64_t)n * HW + p) * C + c] = tile[tx][i];
+        if (p < HW && c < C) st_elem(y, ((int64_t)n * HW + p) * C + c, y_bf16 != 0, tile[tx][i]);
     }
 }
 
@@ -219,6 +219,7 @@ __global__ void fc_split_reduce_kernel(const float* __restrict__ work, float* __
 }
 
 // ---- MaxPool2d(2,2) + fused ReLU backward (VGG19 features), NHWC float4 along C -------------------
+template <bool XB, bool YB>
 __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C4,
                                     int Ho, int Wo, int64_t total) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -227,15 +228,17 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restri
         const int ox = (int)(t % Wo); t /= Wo;
         const int oy = (int)(t % Ho);
         const int n = (int)(t / Ho);
-        const f32x4* p = reinterpret_cast<const f32x4*>(x) + (((int64_t)n * H + 2 * oy) * W + 2 * ox) * C4 + c4;
-        const f32x4 a = p[0], b = p[C4], c = p[(int64_t)W * C4], d = p[(int64_t)W * C4 + C4];
+        const int64_t p = (((int64_t)n * H + 2 * oy) * W + 2 * ox) * C4 + c4;
+        const f32x4 a = ld4<XB>(x, p), b = ld4<XB>(x, p + C4), c = ld4<XB>(x, p + (int64_t)W * C4),
+                    d = ld4<XB>(x, p + (int64_t)W * C4 + C4);
         f32x4 m;
 #pragma unroll
         for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(c[j], d[j]));
-        reinterpret_cast<f32x4*>(y)[e] = m;
+        st4<YB>(y, e, m);
     }
 }
 
+template <bool GB, bool XB, bool DB>
 __global__ void maxpool2_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                          float* __restrict__ dx, int H, int W, int C4, int Ho, int Wo,
                                          int64_t total) {
@@ -248,11 +251,10 @@ __global__ void maxpool2_relu_bwd_kernel(const float* __restrict__ dy, const flo
         const int n = (int)(t / Ho);
         const int64_t base = (((int64_t)n * H + 2 * oy) * W + 2 * ox) * C4 + c4;
         const int64_t offs[4] = {0, C4, (int64_t)W * C4, (int64_t)W * C4 + C4};
-        const f32x4* p = reinterpret_cast<const f32x4*>(x) + base;
         f32x4 v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = p[offs[k]];
-        const f32x4 g = reinterpret_cast<const f32x4*>(dy)[e];
+        for (int k = 0; k < 4; ++k) v[k] = ld4<XB>(x, base + offs[k]);
+        const f32x4 g = ld4<GB>(dy, e);
         f32x4 o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -264,85 +266,95 @@ __global__ void maxpool2_relu_bwd_kernel(const float* __restrict__ dy, const flo
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k][j] = (k == am && mv > 0.f) ? g[j] : 0.f;
         }
-        f32x4* q = reinterpret_cast<f32x4*>(dx) + base;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) q[offs[k]] = o[k];
+        for (int k = 0; k < 4; ++k) st4<DB>(dx, base + offs[k], o[k]);
     }
 }
 
 // odd H/W: the last row / column is not covered by any window -> zero gradient
-__global__ void maxpool2_bwd_edge_kernel(float* __restrict__ dx, int N, int H, int W, int C) {
+__global__ void maxpool2_bwd_edge_kernel(float* __restrict__ dx, int N, int H, int W, int C, int dx_bf16) {
     const int64_t total = (int64_t)N * H * W * C;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t pix = e / C;
         const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
-        if (((H & 1) && yh == H - 1) || ((W & 1) && xw == W - 1)) dx[e] = 0.f;
+        if (((H & 1) && yh == H - 1) || ((W & 1) && xw == W - 1)) st_elem(dx, e, dx_bf16 != 0, 0.f);
     }
 }
 
 __global__ void add_relu_masked_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                       const float* __restrict__ ref, float* __restrict__ out, int64_t n) {
+                                       const float* __restrict__ ref, float* __restrict__ out, int64_t n, int dt) {
+    const bool ab = dt & 1, bb = dt & 2, rb = dt & 4, ob = dt & 8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float m = ref[i] > 0.f ? b[i] : 0.f;
-        out[i] = (a != nullptr ? a[i] : 0.f) + m;
+        const float m = ld_elem(ref, i, rb) > 0.f ? ld_elem(b, i, bb) : 0.f;
+        st_elem(out, i, ob, (a != nullptr ? ld_elem(a, i, ab) : 0.f) + m);
     }
 }
 
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-extern "C" int sisr_maxpool2_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+extern "C" int sisr_maxpool2_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dt,
+                                 void* stream) {
     if (!x || !y || N <= 0 || H < 2 || W < 2 || C <= 0 || (C & 3)) return SISR_E_BADARG;
     const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
     const int64_t total = (int64_t)N * Ho * Wo * C4;
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(blocks), dim3(256), 0, S_(stream), x, y, H, W, C4, Ho, Wo, total);
+    switch (dt & 3) {
+        case 0: hipLaunchKernelGGL((maxpool2_fwd_kernel<false, false>), dim3(blocks), dim3(256), 0, S_(stream), x, y, H, W, C4, Ho, Wo, total); break;
+        case 1: hipLaunchKernelGGL((maxpool2_fwd_kernel<true, false>), dim3(blocks), dim3(256), 0, S_(stream), x, y, H, W, C4, Ho, Wo, total); break;
+        case 2: hipLaunchKernelGGL((maxpool2_fwd_kernel<false, true>), dim3(blocks), dim3(256), 0, S_(stream), x, y, H, W, C4, Ho, Wo, total); break;
+        default: hipLaunchKernelGGL((maxpool2_fwd_kernel<true, true>), dim3(blocks), dim3(256), 0, S_(stream), x, y, H, W, C4, Ho, Wo, total); break;
+    }
     SISR_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int sisr_maxpool2_relu_bwd(const float* dy, const float* x, float* dx, int32_t N, int32_t H, int32_t W,
-                                      int32_t C, void* stream) {
+                                      int32_t C, int32_t dt, void* stream) {
     if (!dy || !x || !dx || N <= 0 || H < 2 || W < 2 || C <= 0 || (C & 3)) return SISR_E_BADARG;
     const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
     const int64_t total = (int64_t)N * Ho * Wo * C4;
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(maxpool2_relu_bwd_kernel, dim3(blocks), dim3(256), 0, S_(stream), dy, x, dx, H, W, C4, Ho, Wo,
-                       total);
+    if ((dt & 7) == 0)
+        hipLaunchKernelGGL((maxpool2_relu_bwd_kernel<false, false, false>), dim3(blocks), dim3(256), 0, S_(stream), dy, x, dx, H, W, C4, Ho, Wo, total);
+    else if ((dt & 7) == 7)
+        hipLaunchKernelGGL((maxpool2_relu_bwd_kernel<true, true, true>), dim3(blocks), dim3(256), 0, S_(stream), dy, x, dx, H, W, C4, Ho, Wo, total);
+    else
+        return SISR_E_UNSUPPORTED;         // all fp32 or all bf16
     SISR_CHECK_LAUNCH();
     if ((H & 1) || (W & 1)) {
-        hipLaunchKernelGGL(maxpool2_bwd_edge_kernel, dim3(1024), dim3(256), 0, S_(stream), dx, N, H, W, C);
+        hipLaunchKernelGGL(maxpool2_bwd_edge_kernel, dim3(1024), dim3(256), 0, S_(stream), dx, N, H, W, C, (dt >> 2) & 1);
         SISR_CHECK_LAUNCH();
     }
     return 0;
 }
 
 extern "C" int sisr_add_relu_masked(const float* a, const float* b, const float* ref, float* out, int64_t n,
-                                    void* stream) {
+                                    int32_t dt, void* stream) {
     if (!b || !ref || !out || n <= 0) return SISR_E_BADARG;
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(add_relu_masked_kernel, dim3(blocks), dim3(256), 0, S_(stream), a, b, ref, out, n);
+    hipLaunchKernelGGL(add_relu_masked_kernel, dim3(blocks), dim3(256), 0, S_(stream), a, b, ref, out, n, dt);
     SISR_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int sisr_nhwc_to_nchw(const float* x, const float* pa, const float* pd, const float* slope_p,
                                  float slope, float* y, int64_t dst_stride, int32_t N, int32_t H, int32_t W,
-                                 int32_t C, void* stream) {
+                                 int32_t C, int32_t x_bf16, void* stream) {
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (pa && !pd) || dst_stride < (int64_t)C * H * W)
         return SISR_E_BADARG;
     const int HW = H * W;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 31) / 32, (C + 31) / 32, N), dim3(SISR_BLOCK), 0, S_(stream),
-                       x, pa, pd, slope_p, slope, y, dst_stride, HW, C);
+                       x, pa, pd, slope_p, slope, y, dst_stride, HW, C, x_bf16);
     SISR_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int sisr_nchw_to_nhwc(const float* x, int64_t src_stride, float* y, int32_t N, int32_t H, int32_t W,
-                                 int32_t C, void* stream) {
+                                 int32_t C, int32_t y_bf16, void* stream) {
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || src_stride < (int64_t)C * H * W) return SISR_E_BADARG;
     const int HW = H * W;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 31) / 32, (C + 31) / 32, N), dim3(SISR_BLOCK), 0, S_(stream),
-                       x, src_stride, y, HW, C);
+                       x, src_stride, y, HW, C, y_bf16);
     SISR_CHECK_LAUNCH();
     return 0;
 }

@@ -93,8 +93,9 @@ __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_reduce_kernel(const SisrBnB
     float ssl = 0.f;
     const float slope = d.slope_p ? d.slope_p[0] : d.slope;
     for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < d.P; p += (int64_t)gridDim.x * PL) {
-        const f32x4 dy = *reinterpret_cast<const f32x4*>(d.dy + p * d.C + c);
-        const f32x4 x = *reinterpret_cast<const f32x4*>(d.x + p * d.C + c);
+        const int64_t i4 = (p * d.C + c) >> 2;
+        const f32x4 dy = d.dy_bf16 ? ld4<true>(d.dy, i4) : ld4<false>(d.dy, i4);
+        const f32x4 x = d.x_bf16 ? ld4<true>(d.x, i4) : ld4<false>(d.x, i4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float gg = dy[j];
@@ -166,6 +167,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_finalize_kernel(const SisrB
 }
 
 // ---- elementwise --------------------------------------------------------------------------------
+template <bool X1B, bool X2B, bool YB>
 __global__ void eltwise_res_affine_kernel(const float* __restrict__ x1, const float* slope1_p, float slope1,
                                           const float* __restrict__ x2, const float* __restrict__ pa,
                                           const float* __restrict__ pd, float* __restrict__ y,
@@ -173,12 +175,12 @@ __global__ void eltwise_res_affine_kernel(const float* __restrict__ x1, const fl
     if (slope1_p != nullptr) slope1 = slope1_p[0];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const f32x4 a = reinterpret_cast<const f32x4*>(x1)[i];
+        const f32x4 a = ld4<X1B>(x1, i);
         f32x4 r;
 #pragma unroll
         for (int j = 0; j < 4; ++j) r[j] = lrelu(a[j], slope1);
         if (x2 != nullptr) {
-            const f32x4 b = reinterpret_cast<const f32x4*>(x2)[i];
+            const f32x4 b = ld4<X2B>(x2, i);
             if (pa != nullptr) {
                 const int c = (int)((i * 4) % C);
 #pragma unroll
@@ -188,10 +190,38 @@ __global__ void eltwise_res_affine_kernel(const float* __restrict__ x1, const fl
                 for (int j = 0; j < 4; ++j) r[j] += b[j];
             }
         }
-        reinterpret_cast<f32x4*>(y)[i] = r;
+        st4<YB>(y, i, r);
     }
 }
 
+// all three tensors bf16, C % 8 == 0: 16-byte accesses (8 elements per thread and step)
+__global__ void eltwise_res_affine_bf16x8_kernel(const float* __restrict__ x1, const float* slope1_p, float slope1,
+                                                 const float* __restrict__ x2, const float* __restrict__ pa,
+                                                 const float* __restrict__ pd, float* __restrict__ y,
+                                                 int64_t n8, int C) {
+    if (slope1_p != nullptr) slope1 = slope1_p[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x8 a = ld8_bf16(x1, i);
+        f32x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = lrelu(a[j], slope1);
+        if (x2 != nullptr) {
+            const f32x8 b = ld8_bf16(x2, i);
+            if (pa != nullptr) {
+                const int c = (int)((i * 8) % C);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] += pa[c + j] * b[j] + pd[c + j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] += b[j];
+            }
+        }
+        st8_bf16(y, i, r);
+    }
+}
+
+template <bool GB, bool PB>
 __global__ void __launch_bounds__(SISR_BLOCK) prelu_slope_partial_kernel(const float* __restrict__ dy,
                                                                          const float* __restrict__ pre,
                                                                          int64_t n, float* work) {
@@ -199,15 +229,15 @@ __global__ void __launch_bounds__(SISR_BLOCK) prelu_slope_partial_kernel(const f
     float s = 0.f;
     const int64_t n4 = n >> 2;                               // 16-byte loads; buffers come from the allocator (aligned)
     for (int64_t i = (int64_t)blockIdx.x * SISR_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * SISR_BLOCK) {
-        const f32x4 p = reinterpret_cast<const f32x4*>(pre)[i], g = reinterpret_cast<const f32x4*>(dy)[i];
+        const f32x4 p = ld4<PB>(pre, i), g = ld4<GB>(dy, i);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (!(p[j] > 0.f)) s += g[j] * p[j];
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
-        const float p = pre[i];
-        if (!(p > 0.f)) s += dy[i] * p;
+        const float p = ld_elem(pre, i, PB);
+        if (!(p > 0.f)) s += ld_elem(dy, i, GB) * p;
     }
     const float t = block_sum(s, scratch);
     if (threadIdx.x == 0) work[blockIdx.x] = t;
@@ -221,14 +251,15 @@ __global__ void __launch_bounds__(SISR_BLOCK) sum_partials_kernel(const float* w
     if (threadIdx.x == 0) out[0] = t;
 }
 
+template <bool AB, bool BB, bool YB>
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
                            int64_t n) {
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
-        reinterpret_cast<f32x4*>(y)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+        st4<YB>(y, i, ld4<AB>(a, i) + ld4<BB>(b, i));
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
-        y[i] = a[i] + b[i];
+        st_elem(y, i, YB, ld_elem(a, i, AB) + ld_elem(b, i, BB));
     }
 }
 
@@ -293,34 +324,61 @@ extern "C" int sisr_bn_bwd_finalize(const SisrBnBwdDesc* d, void* stream) {
 }
 
 extern "C" int sisr_eltwise_res_affine(const float* x1, const float* slope1_p, float slope1, const float* x2,
-                                       const float* pa, const float* pd, float* y, int64_t P, int32_t C,
+                                       const float* pa, const float* pd, float* y, int64_t P, int32_t C, int32_t dt,
                                        void* stream) {
     if (!x1 || !y || P <= 0 || C <= 0 || (C & 3) || (pa && !pd) || (pa && !x2)) return SISR_E_BADARG;
     const int64_t n4 = P * C / 4;
+    const bool x2b = x2 ? (dt & 2) != 0 : (dt & 1) != 0;       // no second operand: its flag does not matter
+    const int key = (dt & 1) | (x2b ? 2 : 0) | (dt & 4);
+    if (key == 7 && !(C & 7)) {
+        const int64_t n8 = n4 / 2;
+        const int blocks = (int)std::min<int64_t>((n8 + 255) / 256, 4096);
+        hipLaunchKernelGGL(eltwise_res_affine_bf16x8_kernel, dim3(blocks), dim3(256), 0, S_(stream), x1, slope1_p, slope1,
+                           x2, pa, pd, y, n8, C);
+        SISR_CHECK_LAUNCH();
+        return 0;
+    }
     const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 4096);
-    hipLaunchKernelGGL(eltwise_res_affine_kernel, dim3(blocks), dim3(256), 0, S_(stream), x1, slope1_p, slope1, x2, pa,
-                       pd, y, n4, C);
+#define SISR_ELT_CASE(K, A, B, Y)                                                                                      \
+    case K:                                                                                                           \
+        hipLaunchKernelGGL((eltwise_res_affine_kernel<A, B, Y>), dim3(blocks), dim3(256), 0, S_(stream), x1, slope1_p, \
+                           slope1, x2, pa, pd, y, n4, C);                                                             \
+        break;
+    switch (key) {
+        SISR_ELT_CASE(0, false, false, false) SISR_ELT_CASE(1, true, false, false) SISR_ELT_CASE(2, false, true, false)
+        SISR_ELT_CASE(3, true, true, false) SISR_ELT_CASE(4, false, false, true) SISR_ELT_CASE(5, true, false, true)
+        SISR_ELT_CASE(6, false, true, true) SISR_ELT_CASE(7, true, true, true)
+    }
+#undef SISR_ELT_CASE
     SISR_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int sisr_prelu_slope_grad(const float* dy, const float* pre, int64_t n, float* work, float* out,
-                                     void* stream) {
+                                     int32_t dt, void* stream) {
     if (!dy || !pre || !work || !out || n <= 0) return SISR_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(pre)) & 15) return SISR_E_BADARG;   // 16-byte loads
     const int blocks = (int)std::min<int64_t>((n + 8191) / 8192, 1024);
-    hipLaunchKernelGGL(prelu_slope_partial_kernel, dim3(blocks), dim3(SISR_BLOCK), 0, S_(stream), dy, pre, n, work);
+    switch (dt & 3) {
+        case 0: hipLaunchKernelGGL((prelu_slope_partial_kernel<false, false>), dim3(blocks), dim3(SISR_BLOCK), 0, S_(stream), dy, pre, n, work); break;
+        case 1: hipLaunchKernelGGL((prelu_slope_partial_kernel<true, false>), dim3(blocks), dim3(SISR_BLOCK), 0, S_(stream), dy, pre, n, work); break;
+        case 2: hipLaunchKernelGGL((prelu_slope_partial_kernel<false, true>), dim3(blocks), dim3(SISR_BLOCK), 0, S_(stream), dy, pre, n, work); break;
+        default: hipLaunchKernelGGL((prelu_slope_partial_kernel<true, true>), dim3(blocks), dim3(SISR_BLOCK), 0, S_(stream), dy, pre, n, work); break;
+    }
     SISR_CHECK_LAUNCH();
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(SISR_BLOCK), 0, S_(stream), work, blocks, out);
     SISR_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int sisr_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
+extern "C" int sisr_add(const float* a, const float* b, float* y, int64_t n, int32_t dt, void* stream) {
     if (!a || !b || !y || n <= 0) return SISR_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y)) & 15) return SISR_E_BADARG;
     const int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 4096);
-    hipLaunchKernelGGL(add_kernel, dim3(blocks), dim3(256), 0, S_(stream), a, b, y, n);
+    if ((dt & 7) == 0) hipLaunchKernelGGL((add_kernel<false, false, false>), dim3(blocks), dim3(256), 0, S_(stream), a, b, y, n);
+    else if ((dt & 7) == 7) hipLaunchKernelGGL((add_kernel<true, true, true>), dim3(blocks), dim3(256), 0, S_(stream), a, b, y, n);
+    else if ((dt & 7) == 4) hipLaunchKernelGGL((add_kernel<false, false, true>), dim3(blocks), dim3(256), 0, S_(stream), a, b, y, n);
+    else return SISR_E_UNSUPPORTED;
     SISR_CHECK_LAUNCH();
     return 0;
 }

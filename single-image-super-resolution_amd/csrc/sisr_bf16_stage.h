@@ -10,12 +10,32 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_rsrc(const void* p, unsigned bytes) { return sisr_rsrc(p, bytes); }
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// gfx950 transposing LDS read (cdna_hip_programming.md T10): per 16-lane group a block of 4 rows x 16 columns of
+// 16-bit elements; lane 4q+p of the group supplies the address of row q, columns 4p..4p+3; lane i receives column i
+// of the 4 rows.  Needs all 64 lanes active and 8-byte aligned addresses.
+__device__ __forceinline__ s16x4 lds_tr16(const __bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+// four bf16 values (two dwords as loaded) -> four floats: a bf16 is the upper half of the float with the same value
+__device__ __forceinline__ f32x4 bf16x4_bits_to_f32(u32x2 w) {
+    f32x4 v;
+    v[0] = __uint_as_float(w[0] << 16); v[1] = __uint_as_float(w[0] & 0xFFFF0000u);
+    v[2] = __uint_as_float(w[1] << 16); v[3] = __uint_as_float(w[1] & 0xFFFF0000u);
+    return v;
+}
+
 // float4 staging with the prologue fixed at compile time, bf16 LDS image.
 // Addressing is the cheap part by construction: a thread's items walk the tile in steps of `ppi` pixels, so
 // its (row, column) and the two offset terms advance by adds; loads are raw buffer loads with a 32-bit byte
 // offset (tensor < 4 GB, checked by the planners) and pixels outside the image get an out-of-range offset,
 // which the hardware answers with zeros -- no divergent branch, no 64-bit address math, no multiplies.
-template <int PRO, int SBQ>
+// XBF: the tensor behind x1 / x2 is stored as bf16 (8-byte loads of the thread's 4 channels) instead of fp32.
+template <int PRO, int SBQ, bool XBF>
 __device__ __forceinline__ void stage_tile_bf16(const OperandView& o, __bf16* lds, int PS, int CK, int c0, int TN,
                                                 int IH, int IW, int n0, int iy_org, int ix_org, int valid_w,
                                                 uint32_t m_iw) {
@@ -49,12 +69,13 @@ __device__ __forceinline__ void stage_tile_bf16(const OperandView& o, __bf16* ld
         const int ij = c / Cq;
         coff = c - ij * Cq; ysh = ij >> 1; xsh = ij & 1; Cp = Cq; Wp = 2 * o.W; Hp = 2 * o.H; mul = 2;
     }
-    const int col_step = mul * Cp * 4, row_step = mul * Wp * Cp * 4, img_step = Hp * Wp * Cp * 4;   // bytes
+    constexpr int EB = XBF ? 2 : 4;                                                                    // bytes per element
+    const int col_step = mul * Cp * EB, row_step = mul * Wp * Cp * EB, img_step = Hp * Wp * Cp * EB;   // bytes
     const unsigned nbytes = (unsigned)o.N * (unsigned)img_step;
     const __amdgpu_buffer_rsrc_t r1 = bf_rsrc(o.x1, nbytes);
     const __amdgpu_buffer_rsrc_t r2 = bf_rsrc(need2 ? o.x2 : o.x1, nbytes);
     // byte offset of the tile origin for this thread's channel group (may be "negative": only used in range)
-    const int base = (((n0 * Hp + iy_org * mul + ysh) * Wp + ix_org * mul + xsh) * Cp + coff) * 4;
+    const int base = (((n0 * Hp + iy_org * mul + ysh) * Wp + ix_org * mul + xsh) * Cp + coff) * EB;
 
     constexpr int SB = need2 ? SBQ / 2 : SBQ;      // loads in flight per thread and operand
     const int ppi = SISR_BLOCK >> lg;              // pixels advanced per item step
@@ -84,8 +105,13 @@ __device__ __forceinline__ void stage_tile_bf16(const OperandView& o, __bf16* ld
             ok[u] = live[u] && c_ok && n_ok && (unsigned)iy < (unsigned)o.H && (unsigned)ix < (unsigned)o.W &&
                     ixl < valid_w;
             const unsigned voff = ok[u] ? (unsigned)(base + ro + xoff) : 0xFFFFFFF0u;
-            a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0));
-            if (need2) b[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0));
+            if (XBF) {
+                a[u] = bf16x4_bits_to_f32(__builtin_amdgcn_raw_buffer_load_b64(r1, voff, 0, 0));
+                if (need2) b[u] = bf16x4_bits_to_f32(__builtin_amdgcn_raw_buffer_load_b64(r2, voff, 0, 0));
+            } else {
+                a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0));
+                if (need2) b[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0));
+            }
             pix += ppi; row += step_rows; ixl += step_cols; roff += d_roff; xoff += d_xoff;
             if (ixl >= IW) { ixl -= IW; ++row; roff += row_step; xoff -= wrap_xoff; }
         }
@@ -105,13 +131,19 @@ __device__ __forceinline__ void stage_tile_bf16(const OperandView& o, __bf16* ld
     }
 }
 
-template <int SBQ = 8>
+// XSEL: 0 = fp32 tensor, 1 = bf16 tensor, -1 = decided at run time by o.bf16
+template <int SBQ = 8, int XSEL = -1>
 __device__ __forceinline__ void stage_operand_tile_bf16(const OperandView& o, __bf16* lds, int PS, int CK, int c0,
                                                         int TN, int IH, int IW, int n0, int iy_org, int ix_org,
                                                         int valid_w, uint32_t m_iw) {
     switch (o.pro) {
-#define SISR_STAGE_CASE(P) \
-    case P: stage_tile_bf16<P, SBQ>(o, lds, PS, CK, c0, TN, IH, IW, n0, iy_org, ix_org, valid_w, m_iw); break;
+#define SISR_STAGE_CASE(P)                                                                                              \
+    case P:                                                                                                             \
+        if (XSEL == 1 || (XSEL < 0 && o.bf16))                                                                          \
+            stage_tile_bf16<P, SBQ, true>(o, lds, PS, CK, c0, TN, IH, IW, n0, iy_org, ix_org, valid_w, m_iw);           \
+        else                                                                                                            \
+            stage_tile_bf16<P, SBQ, false>(o, lds, PS, CK, c0, TN, IH, IW, n0, iy_org, ix_org, valid_w, m_iw);          \
+        break;
         SISR_STAGE_CASE(SISR_PRO_NONE)
         SISR_STAGE_CASE(SISR_PRO_ACT)
         SISR_STAGE_CASE(SISR_PRO_AFFINE_ACT)

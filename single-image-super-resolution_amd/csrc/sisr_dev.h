@@ -58,6 +58,63 @@ __host__ __device__ __forceinline__ uint32_t fdiv_magic(int d) {
 }
 __device__ __forceinline__ int fdiv(int n, uint32_t m) { return m ? (int)__umulhi((unsigned)n, m) : n; }
 
+// ---- bf16 storage (activations / gradients kept as bf16 in HBM by the bf16 build; sisr_hip.h *_bf16 flags) -------
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+// round-to-nearest-even via the hardware conversion (keeps NaN a NaN: MI355X_MICROARCH.md, correctness table)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) {
+    const __bf16 h = (__bf16)v;
+    return __builtin_bit_cast(unsigned short, h);
+}
+// element i of a tensor stored as f32 or bf16
+__device__ __forceinline__ float ld_elem(const void* p, int64_t i, bool bf) {
+    return bf ? bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void st_elem(void* p, int64_t i, bool bf, float v) {
+    if (bf) reinterpret_cast<unsigned short*>(p)[i] = f32_to_bf16_bits(v);
+    else reinterpret_cast<float*>(p)[i] = v;
+}
+// elements [4*i4, 4*i4+4) (8- or 16-byte access)
+template <bool BF>
+__device__ __forceinline__ f32x4 ld4(const void* p, int64_t i4) {
+    if (BF) {
+        const u16x4 h = reinterpret_cast<const u16x4*>(p)[i4];
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = bf16_bits_to_f32(h[j]);
+        return v;
+    }
+    return reinterpret_cast<const f32x4*>(p)[i4];
+}
+template <bool BF>
+__device__ __forceinline__ void st4(void* p, int64_t i4, const f32x4 v) {
+    if (BF) {
+        u16x4 h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = f32_to_bf16_bits(v[j]);
+        reinterpret_cast<u16x4*>(p)[i4] = h;
+    } else {
+        reinterpret_cast<f32x4*>(p)[i4] = v;
+    }
+}
+// elements [8*i8, 8*i8+8) of a bf16 tensor (one 16-byte access)
+__device__ __forceinline__ f32x8 ld8_bf16(const void* p, int64_t i8) {
+    const u16x8 h = reinterpret_cast<const u16x8*>(p)[i8];
+    f32x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = bf16_bits_to_f32(h[j]);
+    return v;
+}
+__device__ __forceinline__ void st8_bf16(void* p, int64_t i8, const f32x8 v) {
+    u16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = f32_to_bf16_bits(v[j]);
+    reinterpret_cast<u16x8*>(p)[i8] = h;
+}
+
 // One input element of a (possibly lazily transformed) operand; see SISR_PRO_* in sisr_hip.h.
 struct OperandView {
     const float *x1, *x2, *pa, *pb, *pd, *ps, *pt;
@@ -65,6 +122,7 @@ struct OperandView {
     int mode;            // SISR_X_*
     int pro;             // SISR_PRO_*
     float slope;
+    int bf16 = 0;        // x1 / x2 are bf16 tensors (pointers still typed float*: only the address is used)
 };
 
 __device__ __forceinline__ int64_t operand_offset(const OperandView& o, int n, int y, int x, int c) {
@@ -121,7 +179,7 @@ __device__ __forceinline__ f32x4 apply4(const f32x4 a, const f32x4 b, const f32x
     return v;
 }
 
-template <int PRO, int SBQ>
+template <int PRO, int SBQ, bool XBF = false>
 __device__ __forceinline__ void stage_tile_vec(const OperandView& o, float* lds, int PS, int CK, int c0,
                                                int TN, int IH, int IW, int n0, int iy_org, int ix_org,
                                                int valid_w) {
@@ -177,9 +235,9 @@ __device__ __forceinline__ void stage_tile_vec(const OperandView& o, float* lds,
             a[u] = zero;
             if (need2) b[u] = zero;
             if (ok[u]) {
-                const int off = ((n * Hp + iy * mul + ysh) * Wp + xsh) * Cp + coff + ix * xstep;
-                a[u] = *reinterpret_cast<const f32x4*>(o.x1 + off);
-                if (need2) b[u] = *reinterpret_cast<const f32x4*>(o.x2 + off);
+                const int off = ((n * Hp + iy * mul + ysh) * Wp + xsh) * Cp + coff + ix * xstep;   // multiple of 4
+                a[u] = ld4<XBF>(o.x1, off >> 2);
+                if (need2) b[u] = ld4<XBF>(o.x2, off >> 2);
             }
             pix += ppi; row += step_rows; ixl += step_cols;
             if (ixl >= IW) { ixl -= IW; ++row; }
@@ -210,8 +268,11 @@ __device__ __forceinline__ void stage_operand_tile(const OperandView& o, float* 
     const int npix = TN * IH * IW;
     if (vec_ok) {
         switch (o.pro) {
-#define SISR_STAGE_CASE(P) \
-    case P: stage_tile_vec<P, SBQ>(o, lds, PS, CK, c0, TN, IH, IW, n0, iy_org, ix_org, valid_w); break;
+#define SISR_STAGE_CASE(P)                                                                                       \
+    case P:                                                                                                      \
+        if (o.bf16) stage_tile_vec<P, SBQ, true>(o, lds, PS, CK, c0, TN, IH, IW, n0, iy_org, ix_org, valid_w);   \
+        else stage_tile_vec<P, SBQ, false>(o, lds, PS, CK, c0, TN, IH, IW, n0, iy_org, ix_org, valid_w);         \
+        break;
             SISR_STAGE_CASE(SISR_PRO_NONE)
             SISR_STAGE_CASE(SISR_PRO_ACT)
             SISR_STAGE_CASE(SISR_PRO_AFFINE_ACT)
@@ -239,8 +300,8 @@ __device__ __forceinline__ void stage_operand_tile(const OperandView& o, float* 
             float v = 0.f;
             if (n < o.N && iy >= 0 && iy < o.H && ix >= 0 && ix < o.W && ixl < valid_w) {
                 const int64_t off = operand_offset(o, n, iy, ix, c);
-                const float a = o.x1[off];
-                const float b = need2 ? o.x2[off] : 0.f;
+                const float a = ld_elem(o.x1, off, o.bf16);
+                const float b = need2 ? ld_elem(o.x2, off, o.bf16) : 0.f;
                 v = operand_apply(o, a, b, c);
             }
             lds[pix * PS + cs] = v;

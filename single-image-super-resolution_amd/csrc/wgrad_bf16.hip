@@ -18,12 +18,6 @@
 
 #include "sisr_bf16_stage.h"
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ s16x4 lds_tr16(const __bf16* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-}
 
 __device__ __forceinline__ bf16x8 frag8(const __bf16* p, int second_off) {
     const s16x4 lo = lds_tr16(p), hi = lds_tr16(p + second_off);
@@ -81,6 +75,7 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
     ox.x1 = d.x1; ox.x2 = d.x2; ox.pa = d.pa; ox.pb = d.pb; ox.pd = d.pd; ox.ps = d.ps; ox.pt = d.pt;
     ox.N = d.N; ox.H = d.H; ox.W = d.W; ox.C = d.Cin; ox.mode = d.x_mode; ox.pro = d.pro_mode;
     ox.slope = d.pro_slope_p ? d.pro_slope_p[0] : d.pro_slope;
+    ox.bf16 = d.x_bf16; og.bf16 = d.g_bf16;
     og.x1 = d.g1; og.x2 = d.g2; og.pa = d.qa; og.pb = d.qb; og.pd = d.qd; og.ps = d.qs; og.pt = d.qt;
     og.N = d.N; og.H = d.Ho; og.W = d.Wo; og.C = d.Cout; og.mode = d.g_mode; og.pro = d.gpro_mode;
     og.slope = d.gpro_slope_p ? d.gpro_slope_p[0] : d.gpro_slope;

@@ -24,6 +24,21 @@ def set_precision(p):
     PRECISION = p
 
 
+def storage_bf16():
+    """bf16 build: NHWC activation / gradient tensors whose channel count is a multiple of 32 live in HBM as bf16
+    (SURVEY 8d's bf16 bytes); arithmetic, accumulation and BatchNorm statistics stay fp32.  SISR_STORAGE=f32 keeps
+    fp32 tensors with bf16 matrix-core operands (round 1's layout; A/B switch)."""
+    return PRECISION == 'bf16' and os.environ.get('SISR_STORAGE', 'bf16') != 'f32'
+
+
+def act_dtype(channels=64):
+    return torch.bfloat16 if storage_bf16() and channels % 32 == 0 else torch.float32
+
+
+def _bf(t):
+    return int(t is not None and t.dtype == torch.bfloat16)
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -70,6 +85,8 @@ class Operand:
         vals = (self.x1, self.x2, self.pa, self.pb, self.pd, self.ps, self.pt)
         for n, v in zip(names[:7], vals):
             setattr(d, n, _ptr(v))
+        assert self.x2 is None or self.x2.dtype == self.x1.dtype, 'operand pair with mixed storage types'
+        setattr(d, 'g_bf16' if g else 'x_bf16', _bf(self.x1))
         setattr(d, names[7], self.mode)
         setattr(d, names[8], self.pro)
         if isinstance(self.slope, torch.Tensor):
@@ -336,11 +353,13 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
         if f.y_mode == L.Y_NCHW:
             out = torch.empty((n, gm.cout, f.Ho, f.Wo), dtype=torch.float32, device=dev)
         elif f.y_mode == L.Y_SHUFFLE2:
-            out = torch.empty((n, 2 * f.Ho, 2 * f.Wo, gm.cout // 4), dtype=torch.float32, device=dev)
+            out = torch.empty((n, 2 * f.Ho, 2 * f.Wo, gm.cout // 4), dtype=act_dtype(gm.cout // 4), device=dev)
         else:
-            out = torch.empty((n, f.Ho, f.Wo, gm.cout), dtype=torch.float32, device=dev)
+            out = torch.empty((n, f.Ho, f.Wo, gm.cout), dtype=act_dtype(gm.cout) if res is None else res.dtype,
+                              device=dev)
     op.fill(f)
     f.wpk, f.bias, f.res, f.y = prep.wpk_fwd.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr()
+    f.y_bf16, f.res_bf16 = _bf(out), _bf(res)
     f.epi_act = epi
     sp = cp = None
     if stats:
@@ -373,7 +392,7 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
         dev = dy_op.x1.device
         assert y_mode == L.Y_NHWC
         complete = all(c is not None for c in prep.plans[1])
-        out = (torch.empty if complete else torch.zeros)((f.N, f.H, f.W, gm.cin), dtype=torch.float32, device=dev)
+        out = (torch.empty if complete else torch.zeros)((f.N, f.H, f.W, gm.cin), dtype=act_dtype(gm.cin), device=dev)
         for cls, buf in zip(prep.plans[1], prep.wpk_dgrad):
             if cls is None:
                 continue
@@ -381,6 +400,7 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
             assert tuple(dy_op.dims) == (d.N, d.H, d.W, d.Cin), (dy_op.dims, (d.N, d.H, d.W, d.Cin))
             dy_op.fill(d)
             d.wpk, d.bias, d.res, d.y = buf.data_ptr(), None, _ptr(res), out.data_ptr()
+            d.y_bf16, d.res_bf16 = _bf(out), _bf(res)
             if cls[3]:
                 L.check(lib.sisr_conv2d_bf16(C.byref(d), _stream()), 'sisr_conv2d_bf16(dgrad s2)')
             else:
@@ -393,15 +413,16 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
     if y_mode == L.Y_NCHW:
         out = torch.empty((d.N, gm.cin, d.Ho, d.Wo), dtype=torch.float32, device=dev)
     else:
-        out = torch.empty((d.N, d.Ho, d.Wo, gm.cin), dtype=torch.float32, device=dev)
+        out = torch.empty((d.N, d.Ho, d.Wo, gm.cin), dtype=act_dtype(gm.cin) if res is None else res.dtype, device=dev)
     dy_op.fill(d)
     d.wpk, d.bias, d.res, d.y = prep.wpk_dgrad.data_ptr(), None, _ptr(res), out.data_ptr()
+    d.y_bf16, d.res_bf16 = _bf(out), _bf(res)
     part = None
     if bnb is not None:
         x, consts, slope = bnb
         assert tuple(x.shape) == tuple(out.shape) and y_mode == L.Y_NHWC
         part = torch.empty((d.plan.n_tiles, 2 * gm.cin + 1), dtype=torch.float32, device=dev)
-        d.bnb_x, d.bnb_part = x.data_ptr(), part.data_ptr()
+        d.bnb_x, d.bnb_part, d.bnbx_bf16 = x.data_ptr(), part.data_ptr(), _bf(x)
         d.bnb_scale, d.bnb_shift, d.bnb_mean, d.bnb_invstd = (consts[0].data_ptr(), consts[1].data_ptr(),
                                                               consts[2].data_ptr(), consts[3].data_ptr())
         d.bnb_act = 0 if slope is None else 1
@@ -537,6 +558,7 @@ def bn_backward(dy, x, consts, gamma, slope=None, part=None):
     dbeta = torch.empty((cch,), dtype=torch.float32, device=dev)
     dslope = torch.empty((1,), dtype=torch.float32, device=dev) if slope is not None else None
     d.dy, d.x = dy.data_ptr(), x.data_ptr()
+    d.dy_bf16, d.x_bf16 = _bf(dy), _bf(x)
     d.scale, d.shift, d.mean, d.invstd = (consts[0].data_ptr(), consts[1].data_ptr(), consts[2].data_ptr(),
                                           consts[3].data_ptr())
     d.gamma, d.work = gamma.data_ptr(), work.data_ptr()
@@ -552,12 +574,13 @@ def bn_backward(dy, x, consts, gamma, slope=None, part=None):
 def eltwise_res_affine(x1, slope1, x2=None, pa=None, pd=None):
     """y = lrelu(x1, slope1) + (pa*x2 + pd | x2 | 0) over NHWC tensors."""
     lib = L.lib()
-    y = torch.empty_like(x1)
     cch = x1.shape[-1]
+    y = torch.empty(x1.shape, dtype=act_dtype(cch), device=x1.device)
     sp, sv = (slope1.data_ptr(), 1.0) if isinstance(slope1, torch.Tensor) else \
         (None, 1.0 if slope1 is None else float(slope1))
+    dt = _bf(x1) | (_bf(x2) << 1) | (_bf(y) << 2)
     L.check(lib.sisr_eltwise_res_affine(x1.data_ptr(), sp, sv, _ptr(x2), _ptr(pa), _ptr(pd), y.data_ptr(),
-                                        x1.numel() // cch, cch, _stream()), 'sisr_eltwise_res_affine')
+                                        x1.numel() // cch, cch, dt, _stream()), 'sisr_eltwise_res_affine')
     return y
 
 
@@ -566,14 +589,16 @@ def prelu_slope_grad(dy, pre):
     work = torch.empty((1024,), dtype=torch.float32, device=dy.device)
     out = torch.empty((1,), dtype=torch.float32, device=dy.device)
     L.check(lib.sisr_prelu_slope_grad(dy.data_ptr(), pre.data_ptr(), dy.numel(), work.data_ptr(),
-                                      out.data_ptr(), _stream()), 'sisr_prelu_slope_grad')
+                                      out.data_ptr(), _bf(dy) | (_bf(pre) << 1), _stream()), 'sisr_prelu_slope_grad')
     return out
 
 
 def add(a, b):
     lib = L.lib()
+    if a.dtype != b.dtype:
+        raise RuntimeError('add: operands with mixed storage types')
     y = torch.empty_like(a)
-    L.check(lib.sisr_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), 'sisr_add')
+    L.check(lib.sisr_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), 7 * _bf(a), _stream()), 'sisr_add')
     return y
 
 
@@ -582,7 +607,7 @@ def require_gpu_tensor(x, what):
         raise RuntimeError('%s: this path runs only on an MI355X device tensor (got %s); there is no '
                            'CPU fallback' % (what, getattr(x, 'device', type(x))))
     if x.dtype != torch.float32:
-        raise RuntimeError('%s: fp32 tensors expected, got %s' % (what, x.dtype))
+        raise RuntimeError('%s: fp32 tensors expected at the module boundary, got %s' % (what, x.dtype))
 
 
 def nhwc_to_nchw(x, out, dst_stride, pa=None, pd=None, slope=None):
@@ -590,12 +615,12 @@ def nhwc_to_nchw(x, out, dst_stride, pa=None, pd=None, slope=None):
     n, h, w, c = x.shape
     sp, sv = (slope.data_ptr(), 1.0) if isinstance(slope, torch.Tensor) else (None, 1.0 if slope is None else float(slope))
     L.check(L.lib().sisr_nhwc_to_nchw(x.data_ptr(), _ptr(pa), _ptr(pd), sp, sv, out.data_ptr(), dst_stride,
-                                      n, h, w, c, _stream()), 'sisr_nhwc_to_nchw')
+                                      n, h, w, c, _bf(x), _stream()), 'sisr_nhwc_to_nchw')
 
 
 def nchw_to_nhwc(src, src_stride, n, h, w, c):
-    y = torch.empty((n, h, w, c), dtype=torch.float32, device=src.device)
-    L.check(L.lib().sisr_nchw_to_nhwc(src.data_ptr(), src_stride, y.data_ptr(), n, h, w, c, _stream()),
+    y = torch.empty((n, h, w, c), dtype=act_dtype(c), device=src.device)
+    L.check(L.lib().sisr_nchw_to_nhwc(src.data_ptr(), src_stride, y.data_ptr(), n, h, w, c, _bf(y), _stream()),
             'sisr_nchw_to_nhwc')
     return y
 
@@ -645,21 +670,24 @@ def act_bwd(dy, ref, kind, slope=0.0):
 
 def maxpool2(x):
     n, h, w, c = x.shape
-    y = torch.empty((n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
-    L.check(L.lib().sisr_maxpool2_fwd(x.data_ptr(), y.data_ptr(), n, h, w, c, _stream()), 'sisr_maxpool2_fwd')
+    y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+    L.check(L.lib().sisr_maxpool2_fwd(x.data_ptr(), y.data_ptr(), n, h, w, c, 3 * _bf(x), _stream()), 'sisr_maxpool2_fwd')
     return y
 
 
 def maxpool2_relu_bwd(dy, x):
     n, h, w, c = x.shape
+    if dy.dtype != x.dtype:
+        raise RuntimeError('maxpool2_relu_bwd: gradient and activation with mixed storage types')
     dx = torch.empty_like(x)
-    L.check(L.lib().sisr_maxpool2_relu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), n, h, w, c, _stream()),
+    L.check(L.lib().sisr_maxpool2_relu_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), n, h, w, c, 7 * _bf(x), _stream()),
             'sisr_maxpool2_relu_bwd')
     return dx
 
 
 def add_relu_masked(a, b, ref):
     out = torch.empty_like(b)
-    L.check(L.lib().sisr_add_relu_masked(_ptr(a), b.data_ptr(), ref.data_ptr(), out.data_ptr(), b.numel(),
+    dt = _bf(a) | (_bf(b) << 1) | (_bf(ref) << 2) | (_bf(out) << 3)
+    L.check(L.lib().sisr_add_relu_masked(_ptr(a), b.data_ptr(), ref.data_ptr(), out.data_ptr(), b.numel(), dt,
                                          _stream()), 'sisr_add_relu_masked')
     return out

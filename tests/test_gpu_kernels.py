@@ -240,15 +240,23 @@ BF16_CASES = [(2, 64, 64, 3, 1, 12, 12), (1, 64, 64, 3, 1, 37, 29), (2, 32, 128,
               (2, 64, 256, 3, 1, 16, 16), (2, 64, 128, 3, 2, 16, 16), (1, 64, 64, 3, 1, 96, 96)]
 
 
+def _storage(monkeypatch, storage):
+    """bf16 build with fp32 tensors (round-1 layout, SISR_STORAGE=f32) or with bf16 tensors in HBM (the default)"""
+    monkeypatch.setenv('SISR_STORAGE', storage)
+    return torch.bfloat16 if storage == 'bf16' else torch.float32
+
+
+@pytest.mark.parametrize('storage', ['f32', 'bf16'])
 @pytest.mark.parametrize('case', BF16_CASES)
-def test_conv_bf16_forward_dgrad_wgrad(E, L, case):
+def test_conv_bf16_forward_dgrad_wgrad(E, L, case, storage, monkeypatch):
+    dt = _storage(monkeypatch, storage)
     n, cin, cout, k, stride, h, w = case
-    x = _rand((n, cin, h, w), 1)
+    x = _rand((n, cin, h, w), 1).to(dt).float()          # values representable in the storage type
     wt = _rand((cout, cin, k, k), 2, (1.0 / (cin * k * k)) ** 0.5 * 1.7)
     b = _rand((cout,), 3, 0.1)
     xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
     y_ref = F.conv2d(xr, wr, br, stride=stride, padding=k // 2)
-    r = _rand(tuple(y_ref.shape), 4)
+    r = _rand(tuple(y_ref.shape), 4).to(dt).float()
     (y_ref * r).sum().backward()
     E.set_precision('bf16')
     try:
@@ -257,9 +265,17 @@ def test_conv_bf16_forward_dgrad_wgrad(E, L, case):
         preps, keep = E.prepare_weights([(ref, n, h, w)], training=True)
         p = preps[0]
         assert p.kinds[0] and p.kinds[2] and (p.kinds[1] or stride == 2)
-        xd, rd = nhwc(x).cuda(), nhwc(r).cuda()
+        xd, rd = nhwc(x).cuda().to(dt), nhwc(r).cuda().to(dt)
         y, sp, cp = E.conv_forward(p, E.Operand.plain(xd), bias=ref.bias, stats=True)
-        assert maxrel(nchw(y), y_ref) < BF16_TOL, 'forward'
+        assert y.dtype == dt
+        assert maxrel(nchw(y.float()), y_ref) < BF16_TOL, 'forward'
+        # BatchNorm statistics of the epilogue (per-tile count / mean / M2 merged here in float64)
+        cnt, mean_t, m2_t = cp.double().cpu(), sp[:, 0].double().cpu(), sp[:, 1].double().cpu()
+        tot = cnt.sum()
+        mean = (cnt[:, None] * mean_t).sum(0) / tot
+        var = (m2_t + cnt[:, None] * (mean_t - mean) ** 2).sum(0) / tot
+        yr = y_ref.detach().double()
+        assert maxrel(mean, yr.mean(dim=(0, 2, 3))) < BF16_TOL and maxrel(var, yr.var(dim=(0, 2, 3), unbiased=False)) < BF16_TOL
         red = E.conv_wgrad(p, E.Operand.plain(xd), E.Operand.plain(rd))
         wg = E.WeightGradBatch()
         wg.add(p, red)
@@ -267,7 +283,8 @@ def test_conv_bf16_forward_dgrad_wgrad(E, L, case):
         assert maxrel(gw, wr.grad) < BF16_TOL, 'wgrad'
         assert maxrel(gb, br.grad) < BF16_TOL, 'bias grad'
         dx = E.conv_dgrad(p, E.Operand.plain(rd))
-        assert maxrel(nchw(dx), xr.grad) < BF16_TOL, 'dgrad'
+        assert dx.dtype == dt
+        assert maxrel(nchw(dx.float()), xr.grad) < BF16_TOL, 'dgrad'
     finally:
         E.set_precision('fp32')
 
@@ -299,13 +316,16 @@ def test_wgrad_bf16_few_channel_output_padded(E, L):
         E.set_precision('fp32')
 
 
+@pytest.mark.parametrize('storage', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape,act', [((2, 64, 64, 12, 12), True), ((1, 64, 64, 37, 29), False), ((3, 32, 64, 6, 6), True)])
-def test_bn_backward_reductions_from_the_conv_epilogue(E, L, shape, act):
+def test_bn_backward_reductions_from_the_conv_epilogue(E, L, shape, act, storage, monkeypatch):
     """conv_dgrad(..., bnb=...): the data-gradient conv (bf16 kernel) also emits the backward reductions of the
     BatchNorm its output arrives at; they must equal the stand-alone reduction kernel run on the same gradient"""
+    dt = _storage(monkeypatch, storage)
     n, cin, cout, h, w = shape
     wt = _rand((cout, cin, 3, 3), 51, (1.0 / (cin * 9)) ** 0.5 * 1.7)
     dy, skip, x = _rand((n, cout, h, w), 52), _rand((n, cin, h, w), 53), _rand((n, cin, h, w), 54, 2.0)
+    x = x.to(dt).float()
     gamma, beta = _rand((cin,), 55) + 1.5, _rand((cin,), 56)
     mean = x.mean(dim=(0, 2, 3))
     invstd = torch.rsqrt(x.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
@@ -316,12 +336,19 @@ def test_bn_backward_reductions_from_the_conv_epilogue(E, L, shape, act):
         ref = FakeConv(wt.cuda(), None, E.ConvGeom(cin, cout, 3, 1, 1))
         p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
         assert E.can_fuse_bn_backward(p)
-        xd = nhwc(x).cuda()
-        g, part = E.conv_dgrad(p, E.Operand.plain(nhwc(dy).cuda()), res=nhwc(skip).cuda(), bnb=(xd, k, slope))
+        xd = nhwc(x).cuda().to(dt)
+        g, part = E.conv_dgrad(p, E.Operand.plain(nhwc(dy).cuda().to(dt)), res=nhwc(skip).cuda().to(dt), bnb=(xd, k, slope))
+        assert g.dtype == dt
+        # the gradient itself: conv-transpose of dy plus the skip gradient
+        g_ref = F.conv_transpose2d(dy.to(dt).float(), wt, padding=1) + skip.to(dt).float()
+        assert maxrel(nchw(g.float()), g_ref) < BF16_TOL
         fused = E.bn_backward(g, xd, k, gamma.cuda(), slope=slope, part=part)
         plain = E.bn_backward(g, xd, k, gamma.cuda(), slope=slope)
+        # fp32 tensors: both read the same gradient.  bf16 tensors: the epilogue sums the fp32 accumulators, the
+        # stand-alone kernel the gradient after its rounding to bf16 (2^-9 relative per element, zero mean)
+        tol = 1e-4 if storage == 'f32' else 5e-3
         for a, b in zip(fused, plain):
             if a is not None:
-                assert maxrel(a, b) < 1e-4
+                assert maxrel(a, b) < tol
     finally:
         E.set_precision('fp32')
