@@ -183,7 +183,7 @@ def _recorded_traffic(kernel_key):
         return None, None
 
 
-def kernel_rooflines(device, precision, iters=40):
+def kernel_rooflines(device, precision, iters=40, only=None):
     """The three trunk kernels (3x3, 64->64 at (16, 96, 96)) launched exactly as inside the step:
        fwd   -- BatchNorm-apply + PReLU prologue, BatchNorm-statistics epilogue           (33 per step)
        dgrad -- BatchNorm-backward prologue, residual add, fused BatchNorm-backward sums  (33 per step)
@@ -230,6 +230,8 @@ def kernel_rooflines(device, precision, iters=40):
              'dgrad': 'conv_mfma_%s_kernel (trunk 3x3 64->64, data-gradient role)' % fam,
              'wgrad': 'wgrad_mfma_%s_kernel + slab reduction (trunk 3x3 64->64)' % fam}
     out_rec = {}
+    if only is not None:                         # developer tools (tools/trace_conv.py, tools/prof_conv.py): one role
+        roles = {r: v for r, v in roles.items() if r in only}
     for role, (fn, per_step, nbytes) in roles.items():
         ms = _time_launches(fn, iters)
         if precision == 'bf16':

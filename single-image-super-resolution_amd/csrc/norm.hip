@@ -194,28 +194,29 @@ __global__ void eltwise_res_affine_kernel(const float* __restrict__ x1, const fl
     }
 }
 
-// all three tensors bf16, C % 8 == 0: 16-byte accesses (8 elements per thread and step)
-__global__ void eltwise_res_affine_bf16x8_kernel(const float* __restrict__ x1, const float* slope1_p, float slope1,
-                                                 const float* __restrict__ x2, const float* __restrict__ pa,
-                                                 const float* __restrict__ pd, float* __restrict__ y,
-                                                 int64_t n8, int C) {
+// all three tensors bf16, 8 | C, C | 2048: 16-byte accesses (8 elements per thread and step).  The grid stride is a
+// multiple of C / 8, so a thread meets the same 8 channels at every step and keeps their scale / shift in registers.
+__global__ void __launch_bounds__(256) eltwise_res_affine_bf16x8_kernel(const float* __restrict__ x1, const float* slope1_p,
+                                                                        float slope1, const float* __restrict__ x2,
+                                                                        const float* __restrict__ pa,
+                                                                        const float* __restrict__ pd, float* __restrict__ y,
+                                                                        int64_t n8, int C) {
     if (slope1_p != nullptr) slope1 = slope1_p[0];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
-         i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)((i0 * 8) % C);
+    f32x8 ka, kd;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ka[j] = pa != nullptr ? pa[c + j] : 1.f; kd[j] = pa != nullptr ? pd[c + j] : 0.f; }
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = i0; i < n8; i += step) {
         const f32x8 a = ld8_bf16(x1, i);
         f32x8 r;
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = lrelu(a[j], slope1);
         if (x2 != nullptr) {
             const f32x8 b = ld8_bf16(x2, i);
-            if (pa != nullptr) {
-                const int c = (int)((i * 8) % C);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) r[j] += pa[c + j] * b[j] + pd[c + j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) r[j] += b[j];
-            }
+            for (int j = 0; j < 8; ++j) r[j] += ka[j] * b[j] + kd[j];
         }
         st8_bf16(y, i, r);
     }
@@ -330,9 +331,10 @@ extern "C" int sisr_eltwise_res_affine(const float* x1, const float* slope1_p, f
     const int64_t n4 = P * C / 4;
     const bool x2b = x2 ? (dt & 2) != 0 : (dt & 1) != 0;       // no second operand: its flag does not matter
     const int key = (dt & 1) | (x2b ? 2 : 0) | (dt & 4);
-    if (key == 7 && !(C & 7)) {
+    if (key == 7 && !(C & 7) && (2048 % C) == 0) {
         const int64_t n8 = n4 / 2;
-        const int blocks = (int)std::min<int64_t>((n8 + 255) / 256, 4096);
+        // 2048 blocks x 256 threads: the grid stride (a multiple of 2048 octets) keeps a thread on the same channels
+        const int blocks = (int)std::min<int64_t>((n8 + 255) / 256, 2048);
         hipLaunchKernelGGL(eltwise_res_affine_bf16x8_kernel, dim3(blocks), dim3(256), 0, S_(stream), x1, slope1_p, slope1,
                            x2, pa, pd, y, n8, C);
         SISR_CHECK_LAUNCH();

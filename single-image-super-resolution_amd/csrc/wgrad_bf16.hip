@@ -98,7 +98,8 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
     for (int a = 0; a < TPW; ++a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
-    float bias_acc = 0.f;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    const bool want_bias = d.bias_slab != nullptr && q == 0;
     WTR(0);
     int titer = 0;
 
@@ -119,21 +120,13 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
         stage_operand_tile_bf16<8>(ox, lds_in, WG_PSX, BF_CK, q * BF_CK, d.TN, IH, IW, n0, oy0 * S - d.pad_y,
                                 ox0 * S - d.pad_x, 1 << 30, d.m_iw);
         WTR(2 + 5 * titer);
-        stage_operand_tile_bf16<8>(og, lds_dy, DS, DCH, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, d.TW, d.m_twp);
+        // the bias gradient is summed from the dy values while they pass through registers (thread = 4 channels of
+        // group tid % (DCH / 4), a share of the pixels): no second pass over the LDS image
+        if (want_bias) stage_operand_tile_bf16<8, -1, true>(og, lds_dy, DS, DCH, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, d.TW, d.m_twp, &bias4);
+        else stage_operand_tile_bf16<8>(og, lds_dy, DS, DCH, co_base, d.TN, d.TH, TWp, n0, oy0, ox0, d.TW, d.m_twp);
         WTR(3 + 5 * titer);
         __syncthreads();
         WTR(4 + 5 * titer);
-        if (d.bias_slab != nullptr && q == 0) {
-            // bias-gradient partial: every thread sums a strided share of the tile's pixels for one channel
-            // (all 256 threads, independent loads) -- combined across the pixel shares after the tile loop
-            const int lgd = d.NJ == 2 ? 6 : 5;                       // DCH = 32 * NJ
-            const int co = tid & (DCH - 1), share = tid >> lgd, nshare = SISR_BLOCK >> lgd;
-            const int npx = d.TN * d.TH * TWp;
-            float s = 0.f;
-#pragma unroll 8
-            for (int px = share; px < npx; px += nshare) s += (float)lds_dy[px * DS + co];
-            bias_acc += s;
-        }
         // ---- pipelined K loop: position (kx, ty) of the NEXT step to fetch; fetching stops at the last step
         const __bf16* dyp = dy0;
         const __bf16* inp = in0;
@@ -184,14 +177,16 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_bf16_kernel(const Si
         }
     }
     WTR(29);
-    if (d.bias_slab != nullptr && q == 0) {
+    if (want_bias) {
         __syncthreads();                                   // LDS is free: all tiles are done
         float* bsh = smem;
-        bsh[tid] = bias_acc;
+        const int G = DCH >> 2;
+        *reinterpret_cast<f32x4*>(bsh + tid * 4) = bias4;
         __syncthreads();
         if (tid < DCH) {
+            const int gq = tid >> 2, j = tid & 3;
             float s = 0.f;
-            for (int k = tid; k < SISR_BLOCK; k += DCH) s += bsh[k];
+            for (int k = gq; k < SISR_BLOCK; k += G) s += bsh[k * 4 + j];        // fixed order: deterministic
             d.bias_slab[(int64_t)blockIdx.x * d.slab_stride + co_base + tid] = s;
         }
     }

@@ -125,10 +125,12 @@ class ConvGeom:
             L.check(lib.sisr_conv2d_plan(C.byref(d)), 'sisr_conv2d_plan(dgrad stride-2 class)')
         return (d, r0y, r0x, bool(bf))
 
-    def plans(self, n, h, w, max_pixel_blocks=512):
+    def plans(self, n, h, w, max_pixel_blocks=None):
         """-> (fwd desc, dgrad desc | [4 class descs] | None, wgrad desc, kinds) where kinds =
         (fwd_bf16, dgrad_bf16, wgrad_bf16) tells which kernel family each template was planned for."""
-        key = (n, h, w, PRECISION)
+        if max_pixel_blocks is None:
+            max_pixel_blocks = int(os.environ.get('SISR_WGRAD_PIXEL_BLOCKS', '512'))      # A/B knob of the wgrad grids
+        key = (n, h, w, PRECISION, storage_bf16(), max_pixel_blocks)
         if key in self._plans:
             return self._plans[key]
         lib = L.lib()

@@ -5,4 +5,4 @@ import bench
 dev = torch.device('cuda', 0)
 prec = os.environ.get('SISR_PRECISION', 'bf16')
 bench.sub('engine').set_precision(prec)
-print(bench.dominant_kernel_roofline(dev, prec, iters=int(os.environ.get('ITERS', '20'))))
+print(bench.kernel_rooflines(dev, prec, iters=int(os.environ.get('ITERS', '20')), only=(os.environ.get('ROLE', 'fwd'),)))

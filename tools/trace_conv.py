@@ -9,7 +9,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import bench
 dev = torch.device('cuda', 0)
 bench.sub('engine').set_precision('bf16')
-print(bench.dominant_kernel_roofline(dev, 'bf16', iters=3))
+role = os.environ.get('ROLE', 'fwd')
+print(bench.kernel_rooflines(dev, 'bf16', iters=3, only=(role,)))
 torch.cuda.synchronize()
 L = C.CDLL(os.environ['SISR_LIB'])
 n_wg, slots = 1152, 16
