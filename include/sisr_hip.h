@@ -307,7 +307,8 @@ int sisr_act_bwd(const float *dy, const float *ref, float *out, int64_t n, int32
  *      (utils.py:16-31: F.interpolate(..., 'bicubic', align_corners=True) + _crop_lr) -------- */
 int sisr_bicubic_fwd(const float *x, float *y, int32_t NC, int32_t H, int32_t W, int32_t Ho,
                      int32_t Wo, int32_t clamp, void *stream);
-/* dx += / = transpose of the interpolation applied to dy (masked by the clamp when y given) */
+/* dx = transpose of the interpolation applied to dy (masked by the clamp when y_clamped is given); gather form:
+ * every input pixel sums the output gradients that read it in a fixed order -- deterministic, no atomics */
 int sisr_bicubic_bwd(const float *dy, const float *y_clamped, float *dx, int32_t NC, int32_t H,
                      int32_t W, int32_t Ho, int32_t Wo, void *stream);
 

@@ -46,29 +46,60 @@ __global__ void bicubic_fwd_kernel(const float* __restrict__ x, float* __restric
     }
 }
 
-// transpose of the interpolation: scatter with float atomics (the tensors are 3-channel images)
-__global__ void bicubic_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yc, float* dx, int NC,
-                                   int H, int W, int Ho, int Wo, float sy, float sx) {
-    const int64_t total = (int64_t)NC * Ho * Wo;
+// weight with which output index `o` reads input index `i` along one axis (taps that the border clamp folds onto
+// the same input index add up)
+__device__ __forceinline__ float cubic_weight_of(int o, float scale, int n_in, int i) {
+    int idx[4];
+    float w[4];
+    cubic_setup(o, scale, n_in, idx, w);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += idx[k] == i ? w[k] : 0.f;
+    return s;
+}
+
+// output indices whose 4 taps can reach input index i: floor(scale * o) in [i - 2, i + 1] (one index of margin
+// on each side; cubic_weight_of() returns 0 for the ones that do not)
+__device__ __forceinline__ void cubic_reach(int i, float scale, int n_out, int& lo, int& hi) {
+    if (scale > 0.f) {
+        lo = max(0, (int)floorf((float)(i - 2) / scale) - 1);
+        hi = min(n_out - 1, (int)ceilf((float)(i + 2) / scale) + 1);
+    } else {
+        lo = 0; hi = n_out - 1;
+    }
+}
+
+// transpose of the interpolation in GATHER form: one thread per input pixel sums, in a fixed order, the output
+// gradients that read it -- deterministic (no atomics), which the unsupervised branch's replay tests rely on
+__global__ void bicubic_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yc, float* __restrict__ dx,
+                                   int NC, int H, int W, int Ho, int Wo, float sy, float sx) {
+    const int64_t total = (int64_t)NC * H * W;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        float g = dy[e];
-        if (yc != nullptr) {   // clamp mask: gradient passes only strictly inside (-1, 1)
-            const float v = yc[e];
-            if (!(v > -1.f && v < 1.f)) g = 0.f;
+        const int ix = (int)(e % W);
+        const int iy = (int)((e / W) % H);
+        const int nc = (int)(e / ((int64_t)W * H));
+        int ylo, yhi, xlo, xhi;
+        cubic_reach(iy, sy, Ho, ylo, yhi);
+        cubic_reach(ix, sx, Wo, xlo, xhi);
+        const float* g = dy + (int64_t)nc * Ho * Wo;
+        const float* v = yc != nullptr ? yc + (int64_t)nc * Ho * Wo : nullptr;
+        float acc = 0.f;
+        for (int oy = ylo; oy <= yhi; ++oy) {
+            const float wy = cubic_weight_of(oy, sy, H, iy);
+            if (wy == 0.f) continue;
+            float row = 0.f;
+            for (int ox = xlo; ox <= xhi; ++ox) {
+                const float wx = cubic_weight_of(ox, sx, W, ix);
+                float gv = g[(int64_t)oy * Wo + ox];
+                if (v != nullptr) {                // clamp mask: gradient passes only strictly inside (-1, 1)
+                    const float c = v[(int64_t)oy * Wo + ox];
+                    if (!(c > -1.f && c < 1.f)) gv = 0.f;
+                }
+                row += wx * gv;
+            }
+            acc += wy * row;
         }
-        if (g == 0.f) continue;
-        const int ox = (int)(e % Wo);
-        const int oy = (int)((e / Wo) % Ho);
-        const int nc = (int)(e / ((int64_t)Wo * Ho));
-        int iy[4], ix[4];
-        float wy[4], wx[4];
-        cubic_setup(oy, sy, H, iy, wy);
-        cubic_setup(ox, sx, W, ix, wx);
-        float* p = dx + (int64_t)nc * H * W;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(p + (int64_t)iy[i] * W + ix[j], g * wy[i] * wx[j]);
+        dx[e] = acc;
     }
 }
 
@@ -89,9 +120,7 @@ extern "C" int sisr_bicubic_bwd(const float* dy, const float* y_clamped, float* 
                                 int32_t Ho, int32_t Wo, void* stream) {
     if (!dy || !dx || NC <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(dx, 0, (size_t)NC * H * W * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-    const int64_t total = (int64_t)NC * Ho * Wo;
+    const int64_t total = (int64_t)NC * H * W;
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(bicubic_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, y_clamped, dx, NC, H, W, Ho, Wo,
                        ac_scale(H, Ho), ac_scale(W, Wo));

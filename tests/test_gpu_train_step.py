@@ -88,3 +88,100 @@ def test_one_training_iteration_matches_oracle():
     sd = net_d.state_dict()
     for k, v in ref[5].items():
         assert rel_err(sd[k].cpu(), v) < TOL, k
+
+
+def test_d_step_with_on_device_experience_replay_matches_oracle():
+    """row f2: the D step of train.py:58-75 with a 3-entry replay list kept on the device
+    (single-image-super-resolution_amd/replay.py) -- D(real) + D(curr_fake) + D(each sampled old fake), every
+    forward with its own BatchNorm statistics and spectral-norm iteration -- against the oracle on the same
+    seeded batches: loss, every D gradient and the advanced SN/BN state at 1e-3"""
+    import numpy as np
+    from oracle import models as om, losses as ol
+    md, rp = pkg('model_discriminator'), pkg('replay')
+    torch.manual_seed(0)
+    net_d = md.Discriminator((3, 32, 32), FEATS, STRIDES)
+    d_state = {k: v.detach().clone() for k, v in net_d.state_dict().items()}
+    g = torch.Generator().manual_seed(7)
+    real = torch.rand(8, 3, 32, 32, generator=g) * 2 - 1
+    curr = torch.rand(8, 3, 32, 32, generator=g) * 2 - 1
+    olds = [torch.rand(8, 3, 32, 32, generator=g) * 2 - 1 for _ in range(3)]
+    ratio = 0.7                                                   # int(3 * 0.7) = 2 old batches per step
+    # ---- oracle (train.py:128-168 on a plain list)
+    st = {k: v.clone() for k, v in d_state.items()}
+    for k in om.param_keys(st):
+        st[k].requires_grad_(True)
+    np.random.seed(3)
+    picked = ol.replay_sample_indices(len(olds), ratio)
+    d_real, new = om.discriminator_forward(st, real, STRIDES, True)
+    st.update(new)
+    d_fakes = []
+    for fk in [curr] + [olds[i] for i in picked]:
+        d_f, new = om.discriminator_forward(st, fk, STRIDES, True)
+        st.update(new)
+        d_fakes.append(d_f)
+    err_ref = ol.adversarial_loss_d(d_real, d_fakes)
+    err_ref.backward()
+    grads_ref = {k: st[k].grad for k in om.param_keys(st)}
+    # ---- HIP path with the device-resident list
+    dev = torch.device('cuda')
+    net_d = net_d.to(dev).train()
+    lst = rp.DeviceReplayList(1000, dev)                          # config.py:50
+    for o in olds:
+        lst.append(o.to(dev))
+    assert len(lst) == 3 and lst[0].is_cuda
+    crit = torch.nn.BCELoss()
+    np.random.seed(3)
+    net_d.zero_grad()
+    _, d_x, err = rp.adversarial_loss_d(net_d, crit, real.to(dev), curr.to(dev), lst,
+                                        torch.full((8,), .9, device=dev), torch.zeros(8, device=dev), ratio)
+    err.backward()
+    assert abs(float(err) - float(err_ref)) < TOL * max(1.0, abs(float(err_ref)))
+    got = {k: p.grad.detach().cpu() for k, p in net_d.named_parameters()}
+    assert grads_close(got, grads_ref, TOL) == []
+    sd = net_d.state_dict()
+    for k in d_state:
+        if k.endswith(('weight_u', 'running_mean', 'running_var')):
+            assert rel_err(sd[k].cpu(), st[k].detach()) < TOL, k
+    lst.store(curr.to(dev), step=0, freq=1)                       # train.py:66-71
+    assert len(lst) == 4 and torch.equal(lst[3].cpu(), curr)
+
+
+def test_unsupervised_branch_content_loss_on_lr_matches_oracle():
+    """row f4: the `content_loss_on_lr` G step (train.py:95-97, config.py:24,128-130,152-161): the generated image is
+    degraded again with the DIFFERENTIABLE lr_from_hr and compared with the LR input through the identity extractor,
+    weight 10 x 10 -- gradients flow through the bicubic backward (gather form: deterministic) into G"""
+    from oracle import models as om, ops as oo
+    mg, mce, ut = pkg('model_generator'), pkg('model_content_extractor'), pkg('utils')
+    torch.manual_seed(0)
+    net_g = mg.Generator(2, 16, 64, [2], use_sn=True)
+    g_state = {k: v.detach().clone() for k, v in net_g.state_dict().items()}
+    hr = torch.rand(4, 3, 24, 24, generator=torch.Generator().manual_seed(9)) * 2.4 - 1.2     # the clamp acts
+    lw = 10.0 * 10.0
+    # ---- oracle
+    st = {k: v.clone() for k, v in g_state.items()}
+    for k in om.param_keys(st):
+        st[k].requires_grad_(True)
+    lr_ref = oo.lr_from_hr(hr, (12, 12))
+    fake_ref, _ = om.generator_forward(st, lr_ref, (2,), True, 0)
+    err_ref = torch.mean(torch.pow(lr_ref - oo.lr_from_hr(fake_ref, (12, 12)), 2)) * lw
+    err_ref.backward()
+    grads_ref = {k: st[k].grad for k in om.param_keys(st)}
+    # ---- HIP path
+    dev = torch.device('cuda')
+    net_g = net_g.to(dev).train()
+    identity = mce.identity()
+
+    def g_step():
+        net_g.load_state_dict(g_state)
+        net_g.zero_grad()
+        img_lr = ut.lr_from_hr(hr.to(dev), (12, 12), device=dev)              # train.py:46
+        fake = net_g(img_lr)
+        fake_bruitee = ut.lr_from_hr(fake, (12, 12), device=dev)              # train.py:96
+        err = torch.mean(torch.pow(identity(img_lr) - identity(fake_bruitee), 2)) * lw
+        err.backward()
+        return err.detach(), {k: p.grad.detach().clone() for k, p in net_g.named_parameters()}
+    err, got = g_step()
+    assert abs(float(err) - float(err_ref)) < TOL * max(1e-3, abs(float(err_ref)))
+    assert grads_close({k: v.cpu() for k, v in got.items()}, grads_ref, 2 * TOL) == []
+    err2, got2 = g_step()                                                     # bit-identical replay: no atomics left
+    assert torch.equal(err, err2) and all(torch.equal(got[k], got2[k]) for k in got)
