@@ -141,6 +141,13 @@ int sisr_wgrad_plan(SisrWgradDesc *d, int32_t max_pixel_blocks);
  * operands; SISR_E_UNSUPPORTED otherwise (callers keep the fp32 kernels for those layers). */
 int sisr_conv2d_plan_bf16(SisrConvDesc *d);
 int sisr_conv2d_bf16(const SisrConvDesc *d, void *stream);
+/* The generator's trunk geometry (3x3, 64 -> 64, stride 1, bf16 NHWC in and out, H % 8 == 0, W % 16 == 0; forward-type
+ * prologue, no residual) runs on a persistent weights-in-registers kernel (conv_trunk.hip) behind sisr_conv2d_bf16;
+ * sisr_conv2d_trunk_eligible tells whether a fully filled descriptor will.  That kernel writes ONE statistics partial
+ * per workgroup instead of one per tile: sisr_conv2d_bf16_parts(d) = rows of stat_part / cnt_part (bnb_part) the launch
+ * of `d` writes -- size those buffers with it (fill geometry, modes, storage flags, res / bnb pointers first). */
+int sisr_conv2d_trunk_eligible(const SisrConvDesc *d);
+int sisr_conv2d_bf16_parts(const SisrConvDesc *d);
 int sisr_wgrad_plan_bf16(SisrWgradDesc *d, int32_t max_pixel_blocks);
 int sisr_conv2d_wgrad_bf16(const SisrWgradDesc *d, void *stream);
 int sisr_conv2d_wgrad_f32(const SisrWgradDesc *d, void *stream);

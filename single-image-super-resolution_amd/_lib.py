@@ -96,6 +96,8 @@ _SIGS = {
     'sisr_conv2d_wgrad_f32': [C.POINTER(WgradDesc), _f],
     'sisr_conv2d_plan_bf16': [C.POINTER(ConvDesc)],
     'sisr_conv2d_bf16': [C.POINTER(ConvDesc), _f],
+    'sisr_conv2d_trunk_eligible': [C.POINTER(ConvDesc)],
+    'sisr_conv2d_bf16_parts': [C.POINTER(ConvDesc)],
     'sisr_wgrad_plan_bf16': [C.POINTER(WgradDesc), _i32],
     'sisr_conv2d_wgrad_bf16': [C.POINTER(WgradDesc), _f],
     'sisr_tr16_selftest': [_f, _f],

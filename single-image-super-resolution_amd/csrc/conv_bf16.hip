@@ -644,6 +644,9 @@ static int launch_conv_bf16(const SisrConvDesc* d, hipStream_t st) {
     return d->y_bf16 ? launch_conv_bf16_t<MSUB, NSUB, TAG, false, true>(d, st) : launch_conv_bf16_t<MSUB, NSUB, TAG, false, false>(d, st);
 }
 
+extern "C" int sisr_conv2d_trunk_eligible(const SisrConvDesc* d);
+int sisr_conv2d_trunk_launch(const SisrConvDesc* d, hipStream_t st);            // conv_trunk.hip
+
 extern "C" int sisr_conv2d_bf16(const SisrConvDesc* d, void* stream) {
     if (!d || !d->x1 || !d->wpk || !d->y) return SISR_E_BADARG;
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
@@ -663,6 +666,10 @@ extern "C" int sisr_conv2d_bf16(const SisrConvDesc* d, void* stream) {
     if (p.CK != BF_CK || p.PS != BF_PS || p.n_tiles <= 0 || p.lds_bytes <= 0 || p.lds_bytes > 160 * 1024)
         return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (sisr_conv2d_trunk_eligible(d)) {                // the generator's trunk geometry: persistent weights-in-registers kernel
+        if (d->stat_part && !d->cnt_part) return SISR_E_BADARG;
+        return sisr_conv2d_trunk_launch(d, st);
+    }
     // TAG only names the symbol (same code): 1 = the generator's trunk geometry in its forward role (BatchNorm
     // statistics epilogue) -- the launch bench.py's roofline probe times --, 2 = the trunk geometry in its other
     // roles (data gradients), 0 = everything else; profiles then report the roles separately

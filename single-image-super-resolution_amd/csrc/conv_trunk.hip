@@ -1,0 +1,395 @@
+// conv_trunk.hip -- the generator's trunk convolution (3x3, 64 -> 64, stride 1, pad 1, bf16 NHWC tensors) as a
+// PERSISTENT, weights-in-registers kernel for gfx950.  It is the same arithmetic as conv_bf16.hip's generic kernel
+// (bf16 MFMA operands, fp32 accumulate, fp32 BatchNorm statistics / reductions) specialised for the one geometry that
+// carries 66 of a training step's ~100 convolution launches (model_generator.py:10,13,39 forward and data gradient).
+//
+// Why a second kernel: the generic kernel is bound by instruction issue and per-workgroup fixed costs, not by HBM or
+// the matrix cores (profiles/r02_pmc_trunk_kernels_generic_per_launch.json: 1,925 VALU + 675 SALU per wave and
+// 128-pixel tile for 72 MFMAs; 1,152 workgroups = 1.5 rounds of 3 per CU, each re-staging 73 KB of weights).  Here:
+//   * ONE workgroup per CU (256 threads, launch bounds 1 wave per SIMD = the whole 512-register file) walks
+//     ~4.5 tiles of 8 x 16 output pixels; wave (h, g) owns output channels 32h..32h+31 of tile rows 4g..4g+3;
+//   * its B operands -- W[32 couts][64 cin][9 taps] = 36 MFMA fragments = 144 VGPRs -- are loaded ONCE per launch and
+//     stay in registers: no weight image in LDS, no weight traffic per tile, half the LDS fragment reads per MFMA;
+//   * the geometry is compile-time (tile 8 x 16, halo 10 x 18, 144-byte LDS pixel stride), so every LDS fragment
+//     address is base + immediate: the MFMA phase is 72 ds_read_b128 + 72 MFMAs and nothing else;
+//   * staging works on 16-byte items (8 channels); the next tile's loads are issued before the MFMA phase of the
+//     current one and committed to the other LDS buffer after it: one barrier per tile, memory latency off the
+//     critical path;
+//   * BatchNorm statistics are carried across the workgroup's tiles in registers: ONE (count, mean, M2) partial per
+//     workgroup (256 per launch instead of 1,152), so the finalize kernels read a quarter of the rows.
+// Requirements (checked by sisr_conv2d_trunk_eligible): Cin = Cout = 64, 3x3, stride 1, pad 1, bf16 NHWC input and
+// output, H % 8 == 0, W % 16 == 0, plain output mode.  Everything else runs on the generic kernels.
+#include "sisr_dev.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "sisr_bf16_stage.h"
+
+#define TK_TH 8
+#define TK_TW 16
+#define TK_IH (TK_TH + 2)
+#define TK_IW (TK_TW + 2)
+#define TK_NPIX (TK_IH * TK_IW)          // 180 halo pixels
+#define TK_PSB 144                        // LDS bytes per halo pixel: 64 bf16 + 16 bytes of padding
+#define TK_ITEMS ((TK_NPIX * 8 + 255) / 256)   // 16-byte staging items per producer thread (6)
+#define TK_YS 68                          // output image: [32 couts][64 pixels + 4] bf16 per wave
+
+// phase timeline, developer build only (make trace; tools/trace_trunk.py): thread 0 stamps the 100 MHz wall clock
+#ifdef SISR_CONV_TRACE
+#define TT_WG 512
+#define TT_SLOTS 64
+__device__ unsigned long long sisr_ttrace_buf[TT_WG * TT_SLOTS];
+#define TT(k)                                                                                                   \
+    do {                                                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < TT_WG && (k) < TT_SLOTS) sisr_ttrace_buf[blockIdx.x * TT_SLOTS + (k)] = wall_clock64(); \
+    } while (0)
+extern "C" int sisr_ttrace_read(void* dst, int n_u64) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sisr_ttrace_buf), (size_t)n_u64 * 8, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define TT(k)
+#endif
+
+struct TrunkArgs {
+    const void *x1, *x2;                  // input operand(s), bf16 NHWC [N][H][W][64]
+    const float *pa, *pb, *pd, *ps, *pt;  // per-channel prologue constants
+    const float* slope_p; float slope;
+    const void* wpk;                      // bf16 image [2 chunks][64 couts][9 taps][32 cin]
+    const float* bias;
+    void* y;                              // bf16 NHWC [N][H][W][64]
+    float *stat_part, *cnt_part;          // forward role: [grid][2][64], [grid]
+    int N, H, W;
+    int tiles_x, per_img, total;          // tiles per row, per image, in all
+    uint32_t m_tiles_x, m_per_img;        // reciprocals (fdiv_magic)
+    int pro;
+};
+
+// prologue of 8 consecutive channels of one pixel: a (and b) hold 8 bf16; returns 8 bf16 packed
+template <int PRO>
+__device__ __forceinline__ u32x4 trunk_apply8(u32x4 a, u32x4 b, const f32x8& ka, const f32x8& kb, const f32x8& kd,
+                                              const f32x8& ks, const f32x8& kt, float slope, bool ok) {
+    if (PRO == SISR_PRO_NONE) return a;                       // zeros outside the image already (hardware OOB)
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = __uint_as_float(a[j] << 16), a1 = __uint_as_float(a[j] & 0xFFFF0000u);
+        float b0 = 0.f, b1 = 0.f;
+        if (PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD) {
+            b0 = __uint_as_float(b[j] << 16); b1 = __uint_as_float(b[j] & 0xFFFF0000u);
+        }
+        float r0, r1;
+        if (PRO == SISR_PRO_ACT) { r0 = lrelu(a0, slope); r1 = lrelu(a1, slope); }
+        else if (PRO == SISR_PRO_AFFINE_ACT) {
+            r0 = lrelu(ka[2 * j] * a0 + kd[2 * j], slope); r1 = lrelu(ka[2 * j + 1] * a1 + kd[2 * j + 1], slope);
+        } else if (PRO == SISR_PRO_BNBWD) {
+            r0 = ka[2 * j] * a0 + kb[2 * j] * b0 + kd[2 * j];
+            r1 = ka[2 * j + 1] * a1 + kb[2 * j + 1] * b1 + kd[2 * j + 1];
+        } else {                                               // BNACT_BWD
+            const float z0 = ks[2 * j] * b0 + kt[2 * j], z1 = ks[2 * j + 1] * b1 + kt[2 * j + 1];
+            const float g0 = z0 > 0.f ? a0 : slope * a0, g1 = z1 > 0.f ? a1 : slope * a1;
+            r0 = ka[2 * j] * g0 + kb[2 * j] * b0 + kd[2 * j];
+            r1 = ka[2 * j + 1] * g1 + kb[2 * j + 1] * b1 + kd[2 * j + 1];
+        }
+        v[2 * j] = r0; v[2 * j + 1] = r1;
+    }
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned lo = f32_to_bf16_bits(v[2 * j]), hi = f32_to_bf16_bits(v[2 * j + 1]);
+        // prologues with f(0) != 0: the halo must be zero AFTER the transform
+        o[j] = (PRO == SISR_PRO_ACT || ok) ? (lo | (hi << 16)) : 0u;
+    }
+    return o;
+}
+
+// Forward role: one-tensor prologue (NONE / ACT / AFFINE_ACT), bias, BatchNorm statistics.
+// 512 threads: waves 0-3 are CONSUMERS (MFMA + epilogue, weights in registers), waves 4-7 are PRODUCERS (they stage
+// the next tile into the other LDS buffer while the consumers work on the current one).  Wave k and wave k + 4 share a
+// SIMD (the dispatcher deals a workgroup's waves over the SIMDs cyclically), so each SIMD overlaps one matrix-heavy
+// and one memory / VALU-heavy wave.  One workgroup barrier per tile.
+#define TK_THREADS 512
+template <int PRO>
+__global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const TrunkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __bf16* out_img = reinterpret_cast<__bf16*>(lds + 2 * TK_NPIX * TK_PSB);            // [4 waves][32][TK_YS]
+    float* red = reinterpret_cast<float*>(lds + 2 * TK_NPIX * TK_PSB + 4 * 32 * TK_YS * 2);   // [4 waves][32][3]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // provably wave-uniform
+    const bool consumer = wave < 4;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int h = wave & 1, g = (wave >> 1) & 1;
+    const unsigned xbytes = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * 128u;
+    auto tile_coords = [&](int T, int& n, int& ty, int& tx) {
+        n = fdiv(T, a.m_per_img);
+        const int rem = T - n * a.per_img;
+        ty = fdiv(rem, a.m_tiles_x);
+        tx = rem - ty * a.tiles_x;
+    };
+
+    // ---- consumer state: B operands (this wave's 32 output channels, 9 taps x 64 input channels) in registers -------
+    bf16x8 bw[9][4];
+    int a_base[2] = {0, 0};
+    float bv = 0.f;
+    float st_shift = 0.f, st_s1 = 0.f, st_s2 = 0.f;     // running statistics of this lane's values, shifted sums
+    int st_n = 0;
+    // ---- producer state: items idx = ptid + 256 k -> halo pixel idx / 8, channel octet ptid % 8 ----------------------
+    const int ptid = tid & 255, oct = tid & 7;
+    const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x8 ka = zero8, kd = zero8;
+    float slope = 1.f;
+    u32x4 sreg[TK_ITEMS];
+    unsigned sok = 0;
+
+    TT(0);
+    if (consumer) {
+        const __amdgpu_buffer_rsrc_t wrs = bf_rsrc(a.wpk, 2u * 64u * 9u * 32u * 2u);
+        const int co = 32 * h + l31;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned off = (unsigned)((((j >> 1) * 64 + co) * 9 + t) * 32 + (j & 1) * 16 + 8 * kk) * 2u;
+                bw[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
+            }
+        // A operand of sub-tile ms: lane (l31, kk) = pixel (tile row 4g + 2ms + (l31 >> 4), column l31 & 15), channels 8kk..
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) a_base[ms] = ((4 * g + 2 * ms + (l31 >> 4)) * TK_IW + (l31 & 15)) * TK_PSB + kk * 16;
+        bv = a.bias != nullptr ? a.bias[32 * h + l31] : 0.f;
+    } else {
+        slope = a.slope_p ? a.slope_p[0] : a.slope;
+        if (PRO == SISR_PRO_AFFINE_ACT) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ka[j] = a.pa[oct * 8 + j]; kd[j] = a.pd[oct * 8 + j]; }
+        }
+    }
+    auto issue = [&](int T) {
+        const __amdgpu_buffer_rsrc_t rx = bf_rsrc(a.x1, xbytes);
+        int n, ty, tx;
+        tile_coords(T, n, ty, tx);
+        sok = 0;
+#pragma unroll
+        for (int k = 0; k < TK_ITEMS; ++k) {
+            const int idx = ptid + k * 256, px = idx >> 3;
+            const int py = px / TK_IW, pxx = px - py * TK_IW;
+            const int iy = ty * TK_TH - 1 + py, ix = tx * TK_TW - 1 + pxx;
+            const bool ok = px < TK_NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned voff = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * 128 + oct * 16) : 0x80000000u;
+            sreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0);
+            sok |= ok ? (1u << k) : 0u;
+        }
+    };
+    auto commit = [&](unsigned char* buf) {
+#pragma unroll
+        for (int k = 0; k < TK_ITEMS; ++k) {
+            const int idx = ptid + k * 256, px = idx >> 3;
+            const u32x4 v = trunk_apply8<PRO>(sreg[k], sreg[k], ka, ka, kd, ka, ka, slope, (sok >> k) & 1u);
+            if (px < TK_NPIX) *reinterpret_cast<u32x4*>(buf + px * TK_PSB + oct * 16) = v;
+        }
+    };
+    __bf16* my_out = out_img + (wave & 3) * (32 * TK_YS);
+    const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+
+    int T = blockIdx.x;
+    if (!consumer && T < a.total) {
+        issue(T);
+        commit(lds);
+    }
+    TT(2);
+    __syncthreads();
+    int cur = 0;
+    int it = 0;
+    for (; T < a.total; T += gridDim.x, cur ^= 1, ++it) {
+        const int Tn = T + gridDim.x;
+        TT(4 + 6 * it);
+        if (!consumer) {
+            // ---- producer: the next tile, into the other buffer ---------------------------------------------------------
+            if (Tn < a.total) {
+                issue(Tn);
+                commit(lds + (cur ^ 1) * (TK_NPIX * TK_PSB));
+            }
+        } else {
+            // ---- consumer: MFMA phase (2 sub-tiles x 9 taps x 4 K-steps; every A address is base + immediate) ... -------
+            f32x16 acc[2];
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[ms][i] = 0.f;
+            const unsigned char* ib = lds + cur * (TK_NPIX * TK_PSB);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int toff = ((t / 3) * TK_IW + (t % 3)) * TK_PSB;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int ms = 0; ms < 2; ++ms) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(ib + a_base[ms] + toff + j * 32);
+                        acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bw[t][j], acc[ms], 0, 0, 0);
+                    }
+                }
+            }
+            TT(6 + 6 * it);
+            // ---- ... and epilogue: bias, statistics, bf16, transposed store -------------------------------------------------
+            const __amdgpu_buffer_rsrc_t ry = bf_rsrc(a.y, xbytes);
+            int n, ty, tx;
+            tile_coords(T, n, ty, tx);
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[ms][i] += bv;
+            if (a.stat_part != nullptr) {
+                if (st_n == 0) {                                    // shift = mean of the first tile's values of this lane
+                    float s = 0.f;
+#pragma unroll
+                    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) s += acc[ms][i];
+                    st_shift = s * (1.f / 32.f);
+                }
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float dv = acc[ms][i] - st_shift;
+                        st_s1 += dv;
+                        st_s2 += dv * dv;
+                    }
+                st_n += 32;
+            }
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bf16x4 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float v = acc[ms][4 * q + j]; hv[j] = (__bf16)v; }
+                    // register group q of sub-tile ms = pixels 32ms + 8q + 4kk .. +3 of this wave's 64
+                    *reinterpret_cast<bf16x4*>(my_out + l31 * TK_YS + 32 * ms + 8 * q + 4 * kk) = hv;
+                }
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {                        // 16-pixel block pb = tile row 4g + pb; group = octet
+                const __bf16* src = my_out + (8 * grp + tq) * TK_YS + 16 * pb + 4 * tp;
+                const s16x4 lo = lds_tr16(src), hi = lds_tr16(src + 4 * TK_YS);
+                const s16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const unsigned vo = (unsigned)(((n * a.H + ty * TK_TH + 4 * g + pb) * a.W + tx * TK_TW + (lane & 15)) * 128 +
+                                               (32 * h + 8 * grp) * 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v8), ry, vo, 0, 0);
+            }
+        }
+        TT(8 + 6 * it);
+        __syncthreads();          // the next tile's image is complete; the consumers have finished reading this one
+        TT(9 + 6 * it);
+    }
+    TT(3);
+
+    // ---- one (count, mean, M2) partial per workgroup and channel ------------------------------------------------------
+    if (a.stat_part != nullptr) {
+        if (consumer) {
+            float n = (float)st_n, mu = 0.f, m2 = 0.f;
+            if (st_n > 0) {
+                const float m1 = st_s1 / n;
+                mu = st_shift + m1;
+                m2 = st_s2 - st_s1 * m1;
+            }
+            // lane halves (kk), then the two row-group waves of this channel half, merged with Chan's formula
+            const float nb = __shfl_xor(n, 32), mub = __shfl_xor(mu, 32), m2b = __shfl_xor(m2, 32);
+            const float nt = n + nb;
+            if (nt > 0.f) { const float dl = mub - mu, f = nb / nt; mu += dl * f; m2 += m2b + dl * dl * n * f; }
+            n = nt;
+            if (kk == 0) { float* r = red + (wave * 32 + l31) * 3; r[0] = n; r[1] = mu; r[2] = m2; }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int hh = tid >> 5, c = tid & 31;               // waves hh (g = 0) and hh + 2 (g = 1)
+            const float* r0 = red + (hh * 32 + c) * 3;
+            const float* r1 = red + ((hh + 2) * 32 + c) * 3;
+            float nn = r0[0], mm = r0[1], qq = r0[2];
+            const float nb = r1[0], nt = nn + nb;
+            if (nt > 0.f) { const float dl = r1[1] - mm, f = nb / nt; mm += dl * f; qq += r1[2] + dl * dl * nn * f; }
+            float* sp = a.stat_part + (int64_t)blockIdx.x * 128 + 32 * hh + c;
+            sp[0] = mm;
+            sp[64] = qq;
+            if (tid == 0) a.cnt_part[blockIdx.x] = nt;
+        }
+    }
+    TT(63);
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------------
+static int trunk_grid(const SisrConvDesc* d) {
+    const int total = d->N * (d->H / TK_TH) * (d->W / TK_TW);
+    static int cus = 0;                         // (one process drives one GPU: queried once)
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 256;
+    }
+    int n_cu = cus;
+    // equal shares: ceil(total / rounds) workgroups, rounds = ceil(total / (CUs x workgroups per CU))
+    int per_cu = 1;
+    if (const char* e = getenv("SISR_TRUNK_WG_PER_CU")) per_cu = std::max(1, std::min(2, atoi(e)));
+    n_cu *= per_cu;
+    const int rounds = (total + n_cu - 1) / n_cu;
+    return (total + rounds - 1) / rounds;
+}
+
+// 1 when this descriptor (geometry + storage flags + fusions requested) can run on the trunk kernel
+extern "C" int sisr_conv2d_trunk_eligible(const SisrConvDesc* d) {
+    const char* sw = getenv("SISR_TRUNK");                      // A/B switch: SISR_TRUNK=0 keeps the generic kernel
+    if (!d || (sw && sw[0] == '0')) return 0;
+    if (d->Cin != 64 || d->Cout != 64 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
+    if (d->x_mode != SISR_X_NHWC || d->y_mode != SISR_Y_NHWC || !d->x_bf16 || !d->y_bf16) return 0;
+    if (d->Ho != d->H || d->Wo != d->W || (d->H % TK_TH) || (d->W % TK_TW)) return 0;
+    if (d->y_sy != 1 || d->y_sx != 1 || d->y_oy || d->y_ox || d->y_H != d->Ho || d->y_W != d->Wo) return 0;
+    if (d->epi_act != SISR_EPI_NONE) return 0;
+    if ((int64_t)d->N * d->H * d->W * 128 >= (1ll << 31)) return 0;
+    if (d->N * (d->H / TK_TH) * (d->W / TK_TW) >= 65536) return 0;
+    const bool fwd_pro = d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT;
+    if (fwd_pro && !d->res && !d->bnb_part) return 1;           // forward role
+    return 0;
+}
+
+// rows of stat_part / cnt_part (or bnb_part) a launch of this descriptor writes: the trunk kernel writes one per
+// workgroup, the generic kernels one per tile (plan.n_tiles)
+extern "C" int sisr_conv2d_bf16_parts(const SisrConvDesc* d) {
+    if (!d) return SISR_E_BADARG;
+    if (sisr_conv2d_trunk_eligible(d)) return trunk_grid(d);
+    return d->plan.n_tiles;
+}
+
+template <int PRO>
+static int launch_trunk_fwd(const TrunkArgs& a, int grid, hipStream_t st) {
+    constexpr int lds_bytes = 2 * TK_NPIX * TK_PSB + 4 * 32 * TK_YS * 2 + 4 * 32 * 3 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_trunk_fwd_kernel<PRO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_trunk_fwd_kernel<PRO>), dim3(grid), dim3(TK_THREADS), lds_bytes, st, a);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+// called by sisr_conv2d_bf16 for eligible descriptors
+int sisr_conv2d_trunk_launch(const SisrConvDesc* d, hipStream_t st) {
+    TrunkArgs a;
+    a.x1 = d->x1; a.x2 = d->x2; a.pa = d->pa; a.pb = d->pb; a.pd = d->pd; a.ps = d->ps; a.pt = d->pt;
+    a.slope_p = d->pro_slope_p; a.slope = d->pro_slope;
+    a.wpk = d->wpk; a.bias = d->bias; a.y = d->y; a.stat_part = d->stat_part; a.cnt_part = d->cnt_part;
+    a.N = d->N; a.H = d->H; a.W = d->W;
+    a.tiles_x = d->W / TK_TW; a.per_img = (d->H / TK_TH) * a.tiles_x; a.total = d->N * a.per_img;
+    a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);
+    a.pro = d->pro_mode;
+    const int grid = trunk_grid(d);
+    switch (d->pro_mode) {
+        case SISR_PRO_NONE: return launch_trunk_fwd<SISR_PRO_NONE>(a, grid, st);
+        case SISR_PRO_ACT: return launch_trunk_fwd<SISR_PRO_ACT>(a, grid, st);
+        case SISR_PRO_AFFINE_ACT: return launch_trunk_fwd<SISR_PRO_AFFINE_ACT>(a, grid, st);
+    }
+    return SISR_E_UNSUPPORTED;
+}

@@ -13,8 +13,10 @@
 //   N = sum n_b ; mean = sum n_b*mean_b / N ; M2 = sum [ M2_b + n_b*(mean_b - mean)^2 ]
 // (algebraically Chan et al.'s pairwise update summed over all tiles; all sums in double).
 // Workgroup = 4 channels x 256 tile-splits (1024 threads): C/4 workgroups, a few tiles per thread.
+#ifndef BNF_SPLITS
 #define BNF_SPLITS 256
 #define BNF_CH 4
+#endif
 // sum over the 256 tile-splits of each of the 4 channels: lanes of one channel combine by shuffles (thread =
 // channel + 4 * split, so a wave holds 16 splits of every channel), the 16 waves through LDS; fixed order
 __device__ __forceinline__ void bnf_reduce2(double& a, double& b, double (*sh)[2][BNF_CH], int cl) {
@@ -29,7 +31,7 @@ __device__ __forceinline__ void bnf_reduce2(double& a, double& b, double (*sh)[2
     for (int w = 0; w < (BNF_SPLITS * BNF_CH) / 64; ++w) { a += sh[w][0][cl]; b += sh[w][1][cl]; }
 }
 
-__global__ void __launch_bounds__(1024) bn_finalize_kernel(
+__global__ void __launch_bounds__(BNF_SPLITS * BNF_CH) bn_finalize_kernel(
     const float* __restrict__ stat_part, const float* __restrict__ cnt_part, int n_tiles, int C,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
@@ -124,29 +126,32 @@ __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_reduce_kernel(const SisrBnB
     if (threadIdx.x == 0) wk[2 * d.C] = tot_sl;
 }
 
+#ifndef BWF_CH
+#define BWF_CH 4
+#endif
 __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_finalize_kernel(const SisrBnBwdDesc d) {
     // workgroup = 4 channels x 64 row-splits over the per-workgroup partial rows of the reduce kernel: a thread
     // sums ~grid/64 rows with independent loads (double accumulation), lanes of one channel combine by
     // shuffles, the 4 waves through LDS -- fixed order, deterministic
-    __shared__ double sh[2][4][4];
+    __shared__ double sh[2][4][BWF_CH];
     __shared__ float scratch[8];
     const int stride = 2 * d.C + 1;
     const double inv_n = 1.0 / (double)d.P;
-    const int cl = threadIdx.x & 3, split = threadIdx.x >> 2, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 4 + cl;
+    const int cl = threadIdx.x & (BWF_CH - 1), split = threadIdx.x / BWF_CH, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * BWF_CH + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < d.C) {
 #pragma unroll 4
-        for (int b = split; b < d.grid; b += 64) {
+        for (int b = split; b < d.grid; b += SISR_BLOCK / BWF_CH) {
             s1 += (double)d.work[(int64_t)b * stride + c];
             s2 += (double)d.work[(int64_t)b * stride + d.C + c];
         }
     }
 #pragma unroll
-    for (int o = 4; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if ((threadIdx.x & 63) < 4) { sh[0][wave][cl] = s1; sh[1][wave][cl] = s2; }
+    for (int o = BWF_CH; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((threadIdx.x & 63) < BWF_CH) { sh[0][wave][cl] = s1; sh[1][wave][cl] = s2; }
     __syncthreads();
-    if (threadIdx.x < 4 && c < d.C) {
+    if (threadIdx.x < BWF_CH && c < d.C) {
         s1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
         s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
         const float ga = d.gamma[c], is = d.invstd[c], mu = d.mean[c];
@@ -274,7 +279,7 @@ extern "C" int sisr_bn_finalize(const float* stat_part, const float* cnt_part, i
     if (!stat_part || !cnt_part || n_tiles <= 0 || C <= 0 || !gamma || !beta || !running_mean || !running_var ||
         !scale || !shift || !save_mean || !save_invstd)
         return SISR_E_BADARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BNF_CH - 1) / BNF_CH), dim3(1024), 0, S_(stream), stat_part,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BNF_CH - 1) / BNF_CH), dim3(BNF_SPLITS * BNF_CH), 0, S_(stream), stat_part,
                        cnt_part, n_tiles, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
                        save_mean, save_invstd);
     SISR_CHECK_LAUNCH();
@@ -310,7 +315,7 @@ extern "C" int sisr_bn_bwd(const SisrBnBwdDesc* d, void* stream) {
     if (lds > 64 * 1024) return SISR_E_UNSUPPORTED;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(d->grid), dim3(SISR_BLOCK), lds, S_(stream), *d);
     SISR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 3) / 4), dim3(SISR_BLOCK), 0, S_(stream), *d);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + BWF_CH - 1) / BWF_CH), dim3(SISR_BLOCK), 0, S_(stream), *d);
     SISR_CHECK_LAUNCH();
     return 0;
 }
@@ -319,7 +324,7 @@ extern "C" int sisr_bn_bwd_finalize(const SisrBnBwdDesc* d, void* stream) {
     if (!d || !d->invstd || !d->mean || !d->gamma || !d->work || !d->qa || !d->qb || !d->qd || !d->dgamma || !d->dbeta ||
         d->grid <= 0 || d->C <= 0 || d->P <= 0)
         return SISR_E_BADARG;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 3) / 4), dim3(SISR_BLOCK), 0, S_(stream), *d);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + BWF_CH - 1) / BWF_CH), dim3(SISR_BLOCK), 0, S_(stream), *d);
     SISR_CHECK_LAUNCH();
     return 0;
 }

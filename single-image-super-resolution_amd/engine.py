@@ -365,8 +365,10 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
     f.epi_act = epi
     sp = cp = None
     if stats:
-        sp = torch.empty((f.plan.n_tiles, 2, gm.cout), dtype=torch.float32, device=dev)
-        cp = torch.empty((f.plan.n_tiles,), dtype=torch.float32, device=dev)
+        # rows of the statistics partials: one per tile, or one per workgroup on the persistent trunk kernel
+        rows = lib.sisr_conv2d_bf16_parts(C.byref(f)) if prep.kinds[0] else f.plan.n_tiles
+        sp = torch.empty((rows, 2, gm.cout), dtype=torch.float32, device=dev)
+        cp = torch.empty((rows,), dtype=torch.float32, device=dev)
         f.stat_part, f.cnt_part = sp.data_ptr(), cp.data_ptr()
     if prep.kinds[0]:
         L.check(lib.sisr_conv2d_bf16(C.byref(f), _stream()), 'sisr_conv2d_bf16(fwd)')

@@ -352,3 +352,59 @@ def test_bn_backward_reductions_from_the_conv_epilogue(E, L, shape, act, storage
                 assert maxrel(a, b) < tol
     finally:
         E.set_precision('fp32')
+
+
+def _merged_stats(sp, cp):
+    cnt, mean_t, m2_t = cp.double().cpu(), sp[:, 0].double().cpu(), sp[:, 1].double().cpu()
+    tot = cnt.sum()
+    mean = (cnt[:, None] * mean_t).sum(0) / tot
+    var = (m2_t + cnt[:, None] * (mean_t - mean) ** 2).sum(0) / tot
+    return float(tot), mean, var
+
+
+@pytest.mark.parametrize('pro', ['none', 'act', 'affine_act'])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 48), (1, 96, 96)])
+def test_trunk_kernel_matches_the_generic_kernel_and_the_reference(E, L, shape, pro, monkeypatch):
+    """conv_trunk.hip (persistent, weights in registers; 3x3 64->64 on bf16 tensors, H % 8 == 0, W % 16 == 0) against
+    the generic bf16 kernel on the same operands and against F.conv2d: output, and the BatchNorm statistics merged from
+    its per-workgroup partials"""
+    n, h, w = shape
+    monkeypatch.setenv('SISR_STORAGE', 'bf16')
+    x = (_rand((n, 64, h, w), 61) * 2.0).bfloat16().float()
+    wt = _rand((64, 64, 3, 3), 62, (1.0 / 576) ** 0.5 * 1.7)
+    b = _rand((64,), 63, 0.1)
+    sc, sh = _rand((64,), 64) * 0.5 + 1.0, _rand((64,), 65) * 0.3
+    slope = torch.tensor([0.2])
+    xin = x
+    if pro == 'act':
+        xin = F.leaky_relu(x, 0.2)
+    elif pro == 'affine_act':
+        xin = F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)
+    y_ref = F.conv2d(xin, wt, b, padding=1)
+    E.set_precision('bf16')
+    try:
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 64, 3, 1, 1))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        xd = nhwc(x).cuda().bfloat16()
+        if pro == 'none':
+            op = E.Operand.plain(xd)
+        elif pro == 'act':
+            op = E.Operand.act(xd, slope.cuda())
+        else:
+            op = E.Operand.affine_act(xd, sc.cuda(), sh.cuda(), slope.cuda())
+        res = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_TRUNK', sw)
+            y, sp, cp = E.conv_forward(p, op, bias=ref.bias, stats=True)
+            res[sw] = (y.float(), sp, cp)
+        assert res['1'][1].shape[0] <= min(res['0'][1].shape[0], 512)  # one partial per workgroup, not per tile
+        assert maxrel(nchw(res['1'][0]), y_ref) < BF16_TOL
+        assert maxrel(res['1'][0], res['0'][0]) < 6e-3                 # same arithmetic, different fp32 summation order
+        t1, m1, v1 = _merged_stats(res['1'][1], res['1'][2])
+        t0, m0, v0 = _merged_stats(res['0'][1], res['0'][2])
+        assert t1 == t0 == n * h * w
+        assert maxrel(m1, m0) < 1e-4 and maxrel(v1, v0) < 1e-4
+        yr = y_ref.double()
+        assert maxrel(m1, yr.mean(dim=(0, 2, 3))) < BF16_TOL and maxrel(v1, yr.var(dim=(0, 2, 3), unbiased=False)) < BF16_TOL
+    finally:
+        E.set_precision('fp32')

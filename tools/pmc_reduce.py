@@ -1,0 +1,28 @@
+"""Reduce the rocprofv3 --pmc passes of tools/pmc_collect.sh to per-launch averages per trunk kernel role and write
+<dir>/pmc_per_launch.json (committed under profiles/ as r02_pmc_trunk_kernels_per_launch.json).  FETCH_SIZE is doubled
+(gfx950: it reports half of the bytes of wide coalesced reads, MI355X_MICROARCH.md section HBM); sizes are in KB."""
+import csv, glob, json, os, sys
+d = sys.argv[1]
+KERNEL = {'fwd': 'conv_mfma_bf16_kernel', 'dgrad': 'conv_mfma_bf16_kernel', 'wgrad': 'wgrad_mfma_bf16_kernel'}
+out = {}
+for role in ('fwd', 'dgrad', 'wgrad'):
+    rec = {}
+    for path in glob.glob(os.path.join(d, role + '_*', '**', '*counter_collection.csv'), recursive=True):
+        per = {}
+        for r in csv.DictReader(open(path)):
+            if KERNEL[role] in r['Kernel_Name']:
+                per.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+        for k, v in per.items():
+            v = v[5:] if len(v) > 8 else v              # drop the warm-up launches
+            rec[k] = sum(v) / len(v)
+    if 'FETCH_SIZE' in rec and 'WRITE_SIZE' in rec:
+        rec['read_bytes_per_launch'] = 2.0 * rec['FETCH_SIZE'] * 1024
+        rec['write_bytes_per_launch'] = rec['WRITE_SIZE'] * 1024
+        rec['traffic_bytes_per_launch'] = rec['read_bytes_per_launch'] + rec['write_bytes_per_launch']
+    if 'SQ_WAVES' in rec and rec['SQ_WAVES'] > 0:
+        w = rec['SQ_WAVES']
+        rec['per_wave'] = {k[3:].lower(): round(rec[k] / w, 1) for k in rec if k.startswith('SQ_INSTS_')}
+    out[role] = rec
+json.dump(out, open(os.path.join(d, 'pmc_per_launch.json'), 'w'), indent=1)
+for role, rec in out.items():
+    print(role, json.dumps(rec.get('per_wave', {})), 'traffic MB %.1f' % (rec.get('traffic_bytes_per_launch', 0) / 1e6))

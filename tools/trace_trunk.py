@@ -1,0 +1,27 @@
+"""Phase timeline of the persistent trunk kernel (developer tool): SISR_LIB=.../libsisr_hip_trace.so python tools/trace_trunk.py"""
+import ctypes as C, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+import bench
+dev = torch.device('cuda', 0)
+print(bench.kernel_rooflines(dev, 'bf16', iters=3, only=(os.environ.get('ROLE', 'fwd'),))[0]['launch_ms'])
+torch.cuda.synchronize()
+L = C.CDLL(os.environ['SISR_LIB'])
+slots = 64
+buf = np.zeros(512 * slots, dtype=np.uint64)
+assert L.sisr_ttrace_read(buf.ctypes.data_as(C.c_void_p), C.c_int(buf.size)) == 0
+t = buf.reshape(512, slots).astype(np.int64) * 10e-3
+t = t[t[:, 0] > 0]
+t0 = t[:, 0].min()
+print('%d workgroups; kernel span %.2f us; lifetime avg %.2f; start spread %.2f' % (len(t), t[:, 63].max() - t0, (t[:, 63] - t[:, 0]).mean(), (t[:, 0] - t0).max()))
+print('prologue (weights to registers / first tile staged, barrier) +%.2f' % (t[:, 4] - t[:, 0]).mean())
+for it in range(8):
+    b = 4 + 6 * it
+    ok = t[:, b + 5] > 0
+    if not ok.any():
+        break
+    d = lambda i, j: (t[ok, j] - t[ok, i]).mean()
+    print('tile %d (n=%d): consumer MFMA %.2f  epilogue %.2f  wait at barrier %.2f   (wave 0 stamps; producers run beside)' % (
+        it, ok.sum(), d(b, b + 2), d(b + 2, b + 4), d(b + 4, b + 5)))
+print('stats tail +%.2f' % (t[:, 63] - t[:, 3]).mean())
