@@ -59,6 +59,12 @@ struct TrunkArgs {
     const float* bias;
     void* y;                              // bf16 NHWC [N][H][W][64]
     float *stat_part, *cnt_part;          // forward role: [grid][2][64], [grid]
+    // data-gradient role: residual (skip gradient) added to the output; the output is the gradient arriving at a
+    // BatchNorm whose input is bnb_x: its backward reductions (SisrConvDesc.bnb_*), one row [2*64+1] per workgroup
+    const void *res, *bnb_x;
+    const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd, *bnb_slope_p;
+    float bnb_slope; int bnb_act;
+    float* bnb_part;
     int N, H, W;
     int tiles_x, per_img, total;          // tiles per row, per image, in all
     uint32_t m_tiles_x, m_per_img;        // reciprocals (fdiv_magic)
@@ -316,6 +322,244 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     TT(63);
 }
 
+
+// Data-gradient role: two-tensor prologue (BNBWD / BNACT_BWD: the gradient and the forward activation of the BatchNorm
+// being differentiated), optional residual (the skip gradient) and optional fused backward reductions of the NEXT
+// BatchNorm of the chain.  Same producer / consumer structure; the producers also copy the residual and BatchNorm-input
+// tiles of the NEXT tile into pixel-major LDS images ([128 pixels][64] bf16, double-buffered) with LDS-direct loads
+// (buffer_load_dwordx4 ... lds: no staging registers), from which the consumers fetch them in accumulator layout with
+// ds_read_b64_tr_b16.  A direct load lays a wave's 64 x 16 bytes down linearly, so rows cannot be padded; instead the
+// 16-byte slot s of pixel p holds channel octet s ^ 2 (p & 3), which spreads the 4 pixel rows of a transposing read
+// over the banks.  The reductions are carried across the workgroup's tiles in registers: one partial row per workgroup.
+#define TK_RS 64
+#define TK_IMG (128 * TK_RS * 2)                 // bytes of one residual / BatchNorm-input image
+#define TK_KOFF (4 * 32 * 2 + 4)                 // prologue constants inside the reduction scratch: [5][64] floats
+#define TK_RED_BYTES 4096
+template <int PRO>
+__global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const TrunkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __bf16* out_img = reinterpret_cast<__bf16*>(lds + 2 * TK_NPIX * TK_PSB);            // [4 waves][32][TK_YS]
+    float* red = reinterpret_cast<float*>(lds + 2 * TK_NPIX * TK_PSB + 4 * 32 * TK_YS * 2);   // [4 waves][32][2] + [4]
+    float* kst = red + TK_KOFF;                                                          // a, b, d, s, t: [5][64]
+    unsigned char* img0 = lds + 2 * TK_NPIX * TK_PSB + 4 * 32 * TK_YS * 2 + TK_RED_BYTES;   // [2 buffers][res, bnb_x][TK_IMG]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int h = wave & 1, g = (wave >> 1) & 1;
+    const bool has_r = a.res != nullptr, has_x = a.bnb_part != nullptr;                 // uniform
+    const unsigned xbytes = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * 128u;
+    auto tile_coords = [&](int T, int& n, int& ty, int& tx) {
+        n = fdiv(T, a.m_per_img);
+        const int rem = T - n * a.per_img;
+        ty = fdiv(rem, a.m_tiles_x);
+        tx = rem - ty * a.tiles_x;
+    };
+
+    // ---- consumer state ---------------------------------------------------------------------------------------------
+    bf16x8 bw[9][4];
+    int a_base[2] = {0, 0};
+    float b_sc = 0.f, b_sf = 0.f, b_mu = 0.f, b_is = 0.f, b_slope = 1.f;
+    float rs1 = 0.f, rs2 = 0.f, rsl = 0.f;            // running sums of this lane's channel: g, g*xhat, slope term
+    // ---- producer state ---------------------------------------------------------------------------------------------
+    const int ptid = tid & 255, oct = tid & 7;
+    float slope = 1.f;
+    u32x4 sa[TK_ITEMS], sb[TK_ITEMS];
+    unsigned sok = 0;
+
+    // the per-channel prologue constants live in LDS (re-read at every commit: 40 registers the producers would
+    // otherwise hold across the tile loop, on top of the consumers' 144 weight registers)
+    if (tid < 64) {
+        kst[tid] = a.pa[tid]; kst[64 + tid] = a.pb[tid]; kst[128 + tid] = a.pd[tid];
+        kst[192 + tid] = PRO == SISR_PRO_BNACT_BWD ? a.ps[tid] : 0.f;
+        kst[256 + tid] = PRO == SISR_PRO_BNACT_BWD ? a.pt[tid] : 0.f;
+    }
+    __syncthreads();
+    if (consumer) {
+        const __amdgpu_buffer_rsrc_t wrs = bf_rsrc(a.wpk, 2u * 64u * 9u * 32u * 2u);
+        const int co = 32 * h + l31;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned off = (unsigned)((((j >> 1) * 64 + co) * 9 + t) * 32 + (j & 1) * 16 + 8 * kk) * 2u;
+                bw[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
+            }
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) a_base[ms] = ((4 * g + 2 * ms + (l31 >> 4)) * TK_IW + (l31 & 15)) * TK_PSB + kk * 16;
+        if (has_x) {
+            b_sc = a.bnb_scale[co]; b_sf = a.bnb_shift[co]; b_mu = a.bnb_mean[co]; b_is = a.bnb_invstd[co];
+            b_slope = a.bnb_slope_p ? a.bnb_slope_p[0] : a.bnb_slope;
+        }
+    } else {
+        slope = a.slope_p ? a.slope_p[0] : a.slope;
+    }
+    auto issue = [&](int T, int b) {
+        const __amdgpu_buffer_rsrc_t r1 = bf_rsrc(a.x1, xbytes), r2 = bf_rsrc(a.x2, xbytes);
+        int n, ty, tx;
+        tile_coords(T, n, ty, tx);
+        sok = 0;
+#pragma unroll
+        for (int k = 0; k < TK_ITEMS; ++k) {
+            const int idx = ptid + k * 256, px = idx >> 3;
+            const int py = px / TK_IW, pxx = px - py * TK_IW;
+            const int iy = ty * TK_TH - 1 + py, ix = tx * TK_TW - 1 + pxx;
+            const bool ok = px < TK_NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned voff = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * 128 + oct * 16) : 0x80000000u;
+            sa[k] = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0);
+            sb[k] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0);
+            sok |= ok ? (1u << k) : 0u;
+        }
+        if (has_r || has_x) {
+            // the tile's own 128 pixels x 8 octets, LDS-direct: producer wave pw lays down 1 KB chunks 4 pw + k (8 pixels
+            // each); lane = (pixel lane >> 3, slot lane & 7) fetches octet slot ^ 2 (pixel & 3)
+            const __amdgpu_buffer_rsrc_t q1 = bf_rsrc(has_r ? a.res : a.bnb_x, xbytes), q2 = bf_rsrc(has_x ? a.bnb_x : a.res, xbytes);
+            unsigned char* ir = img0 + b * (2 * TK_IMG);
+            const int pw = wave & 3;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = 4 * pw + k, m = 8 * c + (lane >> 3);                  // tile pixel m = row (m >> 4), col (m & 15)
+                const int o = (lane & 7) ^ (2 * (m & 3));
+                const unsigned voff = (unsigned)(((n * a.H + ty * TK_TH + (m >> 4)) * a.W + tx * TK_TW + (m & 15)) * 128 + o * 16);
+                if (has_r)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(q1, (__attribute__((address_space(3))) void*)(ir + c * 1024),
+                                                             16, voff, 0, 0, 0);
+                if (has_x)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(q2, (__attribute__((address_space(3))) void*)(ir + TK_IMG + c * 1024),
+                                                             16, voff, 0, 0, 0);
+            }
+        }
+    };
+    auto commit = [&](int b) {
+        unsigned char* buf = lds + b * (TK_NPIX * TK_PSB);
+        const f32x8 ka = *reinterpret_cast<const f32x8*>(kst + oct * 8), kb = *reinterpret_cast<const f32x8*>(kst + 64 + oct * 8),
+                    kd = *reinterpret_cast<const f32x8*>(kst + 128 + oct * 8);
+        f32x8 ks = ka, kt = ka;
+        if (PRO == SISR_PRO_BNACT_BWD) {
+            ks = *reinterpret_cast<const f32x8*>(kst + 192 + oct * 8);
+            kt = *reinterpret_cast<const f32x8*>(kst + 256 + oct * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < TK_ITEMS; ++k) {
+            const int idx = ptid + k * 256, px = idx >> 3;
+            const u32x4 v = trunk_apply8<PRO>(sa[k], sb[k], ka, kb, kd, ks, kt, slope, (sok >> k) & 1u);
+            if (px < TK_NPIX) *reinterpret_cast<u32x4*>(buf + px * TK_PSB + oct * 16) = v;
+        }
+    };
+    __bf16* my_out = out_img + (wave & 3) * (32 * TK_YS);
+    const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+
+    int T = blockIdx.x;
+    if (!consumer && T < a.total) {
+        issue(T, 0);
+        commit(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (; T < a.total; T += gridDim.x, cur ^= 1) {
+        const int Tn = T + gridDim.x;
+        if (!consumer) {
+            if (Tn < a.total) {
+                issue(Tn, cur ^ 1);
+                commit(cur ^ 1);
+            }
+        } else {
+            f32x16 acc[2];
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[ms][i] = 0.f;
+            const unsigned char* ib = lds + cur * (TK_NPIX * TK_PSB);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int toff = ((t / 3) * TK_IW + (t % 3)) * TK_PSB;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int ms = 0; ms < 2; ++ms) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(ib + a_base[ms] + toff + j * 32);
+                        acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bw[t][j], acc[ms], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- epilogue: residual, BatchNorm-backward reductions, bf16, transposed store -------------------------------
+            const __amdgpu_buffer_rsrc_t ry = bf_rsrc(a.y, xbytes);
+            int n, ty, tx;
+            tile_coords(T, n, ty, tx);
+            if (has_r || has_x) {
+                const __bf16* ir = reinterpret_cast<const __bf16*>(img0 + cur * (2 * TK_IMG));
+                const __bf16* ix_ = ir + TK_IMG / 2;
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        // this 16-lane group's block: pixels 64g + 32ms + 8q + 4kk .. +3 (rows), channels 32h + 16 (l31 >> 4) ..
+                        // (row tq of the read = pixel with (pixel & 3) == tq: its octets sit at slot octet ^ 2 tq)
+                        const int oct_r = (4 * h + 2 * (grp & 1) + (tp >> 1)) ^ (2 * tq);
+                        const int off = (64 * g + 32 * ms + 8 * q + 4 * (grp >> 1) + tq) * TK_RS + 8 * oct_r + 4 * (tp & 1);
+                        s16x4 pr, px4;
+                        if (has_r) pr = lds_tr16(ir + off);
+                        if (has_x) px4 = lds_tr16(ix_ + off);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float gv = acc[ms][4 * q + j];
+                            if (has_r) gv += bf16_bits_to_f32((unsigned short)pr[j]);
+                            acc[ms][4 * q + j] = gv;
+                            if (has_x) {
+                                const float xv = bf16_bits_to_f32((unsigned short)px4[j]);
+                                if (a.bnb_act) {
+                                    const float z = b_sc * xv + b_sf;
+                                    if (!(z > 0.f)) { rsl += gv * z; gv *= b_slope; }
+                                }
+                                rs1 += gv;
+                                rs2 += gv * ((xv - b_mu) * b_is);
+                            }
+                        }
+                    }
+            }
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bf16x4 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float v = acc[ms][4 * q + j]; hv[j] = (__bf16)v; }
+                    *reinterpret_cast<bf16x4*>(my_out + l31 * TK_YS + 32 * ms + 8 * q + 4 * kk) = hv;
+                }
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                const __bf16* src = my_out + (8 * grp + tq) * TK_YS + 16 * pb + 4 * tp;
+                const s16x4 lo = lds_tr16(src), hi = lds_tr16(src + 4 * TK_YS);
+                const s16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const unsigned vo = (unsigned)(((n * a.H + ty * TK_TH + 4 * g + pb) * a.W + tx * TK_TW + (lane & 15)) * 128 +
+                                               (32 * h + 8 * grp) * 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v8), ry, vo, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- one row of BatchNorm-backward partial sums per workgroup ----------------------------------------------------
+    if (has_x) {
+        if (consumer) {
+            rs1 += __shfl_xor(rs1, 32);
+            rs2 += __shfl_xor(rs2, 32);
+            if (kk == 0) { red[(wave * 32 + l31) * 2] = rs1; red[(wave * 32 + l31) * 2 + 1] = rs2; }
+            const float ws = wave_sum(rsl);
+            if (lane == 0) red[256 + wave] = ws;
+        }
+        __syncthreads();
+        float* wk = a.bnb_part + (int64_t)blockIdx.x * 129;
+        if (tid < 64) {
+            const int hh = tid >> 5, c = tid & 31;               // waves hh (g = 0) and hh + 2 (g = 1), fixed order
+            wk[tid] = red[(hh * 32 + c) * 2] + red[((hh + 2) * 32 + c) * 2];
+            wk[64 + tid] = red[(hh * 32 + c) * 2 + 1] + red[((hh + 2) * 32 + c) * 2 + 1];
+        }
+        if (tid == 0) wk[128] = (red[256] + red[257]) + (red[258] + red[259]);
+    }
+}
+
 // ---- host ----------------------------------------------------------------------------------------------------------
 static int trunk_grid(const SisrConvDesc* d) {
     const int total = d->N * (d->H / TK_TH) * (d->W / TK_TW);
@@ -349,6 +593,8 @@ extern "C" int sisr_conv2d_trunk_eligible(const SisrConvDesc* d) {
     if (d->N * (d->H / TK_TH) * (d->W / TK_TW) >= 65536) return 0;
     const bool fwd_pro = d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT;
     if (fwd_pro && !d->res && !d->bnb_part) return 1;           // forward role
+    const bool bwd_pro = d->pro_mode == SISR_PRO_BNBWD || d->pro_mode == SISR_PRO_BNACT_BWD;
+    if (bwd_pro && !d->stat_part && !d->bias && (!d->res || d->res_bf16) && (!d->bnb_part || d->bnbx_bf16)) return 2;   // data-gradient role
     return 0;
 }
 
@@ -375,6 +621,21 @@ static int launch_trunk_fwd(const TrunkArgs& a, int grid, hipStream_t st) {
     return 0;
 }
 
+template <int PRO>
+static int launch_trunk_bwd(const TrunkArgs& a, int grid, bool images, hipStream_t st) {
+    const int lds_bytes = 2 * TK_NPIX * TK_PSB + 4 * 32 * TK_YS * 2 + TK_RED_BYTES + (images ? 4 * TK_IMG : 0);
+    static int lds_max = 0;
+    if (lds_bytes > lds_max) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_trunk_bwd_kernel<PRO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        lds_max = lds_bytes;
+    }
+    hipLaunchKernelGGL((conv_trunk_bwd_kernel<PRO>), dim3(grid), dim3(TK_THREADS), lds_bytes, st, a);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
 // called by sisr_conv2d_bf16 for eligible descriptors
 int sisr_conv2d_trunk_launch(const SisrConvDesc* d, hipStream_t st) {
     TrunkArgs a;
@@ -385,7 +646,12 @@ int sisr_conv2d_trunk_launch(const SisrConvDesc* d, hipStream_t st) {
     a.tiles_x = d->W / TK_TW; a.per_img = (d->H / TK_TH) * a.tiles_x; a.total = d->N * a.per_img;
     a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);
     a.pro = d->pro_mode;
+    a.res = d->res; a.bnb_x = d->bnb_x; a.bnb_scale = d->bnb_scale; a.bnb_shift = d->bnb_shift; a.bnb_mean = d->bnb_mean;
+    a.bnb_invstd = d->bnb_invstd; a.bnb_slope_p = d->bnb_slope_p; a.bnb_slope = d->bnb_slope; a.bnb_act = d->bnb_act;
+    a.bnb_part = d->bnb_part;
     const int grid = trunk_grid(d);
+    if (d->pro_mode == SISR_PRO_BNBWD) return launch_trunk_bwd<SISR_PRO_BNBWD>(a, grid, d->res || d->bnb_part, st);
+    if (d->pro_mode == SISR_PRO_BNACT_BWD) return launch_trunk_bwd<SISR_PRO_BNACT_BWD>(a, grid, d->res || d->bnb_part, st);
     switch (d->pro_mode) {
         case SISR_PRO_NONE: return launch_trunk_fwd<SISR_PRO_NONE>(a, grid, st);
         case SISR_PRO_ACT: return launch_trunk_fwd<SISR_PRO_ACT>(a, grid, st);

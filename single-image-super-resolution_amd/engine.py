@@ -425,8 +425,11 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
     if bnb is not None:
         x, consts, slope = bnb
         assert tuple(x.shape) == tuple(out.shape) and y_mode == L.Y_NHWC
-        part = torch.empty((d.plan.n_tiles, 2 * gm.cin + 1), dtype=torch.float32, device=dev)
-        d.bnb_x, d.bnb_part, d.bnbx_bf16 = x.data_ptr(), part.data_ptr(), _bf(x)
+        d.bnb_x, d.bnbx_bf16 = x.data_ptr(), _bf(x)
+        d.bnb_part = d.y                            # (any non-null value: the row count depends on the fusions requested)
+        rows = lib.sisr_conv2d_bf16_parts(C.byref(d)) if prep.kinds[1] else d.plan.n_tiles
+        part = torch.empty((rows, 2 * gm.cin + 1), dtype=torch.float32, device=dev)
+        d.bnb_part = part.data_ptr()
         d.bnb_scale, d.bnb_shift, d.bnb_mean, d.bnb_invstd = (consts[0].data_ptr(), consts[1].data_ptr(),
                                                               consts[2].data_ptr(), consts[3].data_ptr())
         d.bnb_act = 0 if slope is None else 1

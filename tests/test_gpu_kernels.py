@@ -408,3 +408,65 @@ def test_trunk_kernel_matches_the_generic_kernel_and_the_reference(E, L, shape, 
         assert maxrel(m1, yr.mean(dim=(0, 2, 3))) < BF16_TOL and maxrel(v1, yr.var(dim=(0, 2, 3), unbiased=False)) < BF16_TOL
     finally:
         E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('pro,res,bnb', [('bnbwd', False, None), ('bnbwd', True, 'plain'), ('bnact_bwd', True, 'act'),
+                                         ('bnact_bwd', False, 'plain'), ('bnact_bwd', True, None), ('bnbwd', False, 'act')])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 48), (1, 96, 96)])
+def test_trunk_kernel_data_gradient_role(E, L, shape, pro, res, bnb, monkeypatch):
+    """conv_trunk.hip, data-gradient role: two-tensor BatchNorm-backward prologue (with / without the activation),
+    skip gradient added in the epilogue, backward reductions of the next BatchNorm from the epilogue -- against the
+    generic bf16 kernel on the same operands and against conv_transpose2d of the prologue written out in fp32"""
+    n, h, w = shape
+    monkeypatch.setenv('SISR_STORAGE', 'bf16')
+    bf = lambda t: t.bfloat16().float()
+    g_in, c = bf(_rand((n, 64, h, w), 71)), bf(_rand((n, 64, h, w), 72) * 2.0)
+    wt = _rand((64, 64, 3, 3), 73, (1.0 / 576) ** 0.5 * 1.7)
+    qa, qb, qd = _rand((64,), 74) * 0.3 + 1.0, _rand((64,), 75) * 0.2, _rand((64,), 76) * 0.1
+    ks, kt = _rand((64,), 77) * 0.5 + 1.0, _rand((64,), 78) * 0.3
+    slope = torch.tensor([0.2])
+    skip = bf(_rand((n, 64, h, w), 79))
+    xb = bf(_rand((n, 64, h, w), 80) * 2.0)
+    bc = lambda v: v[None, :, None, None]
+    gg = g_in
+    if pro == 'bnact_bwd':
+        z = bc(ks) * c + bc(kt)
+        gg = torch.where(z > 0, g_in, 0.2 * g_in)
+    dy_ref = bc(qa) * gg + bc(qb) * c + bc(qd)
+    out_ref = F.conv_transpose2d(dy_ref, wt, padding=1) + (skip if res else 0.0)
+    gamma, beta = _rand((64,), 81) + 1.5, _rand((64,), 82)
+    mean = xb.mean(dim=(0, 2, 3))
+    invstd = torch.rsqrt(xb.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    kb = torch.stack([gamma * invstd, beta - mean * gamma * invstd, mean, invstd]).cuda()
+    E.set_precision('bf16')
+    try:
+        ref = FakeConv(wt.cuda(), None, E.ConvGeom(64, 64, 3, 1, 1))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        gd, cd = nhwc(g_in).cuda().bfloat16(), nhwc(c).cuda().bfloat16()
+        kw = dict(pa=qa.cuda(), pb=qb.cuda(), pd=qd.cuda())
+        if pro == 'bnact_bwd':
+            kw.update(ps=ks.cuda(), pt=kt.cuda(), slope=slope.cuda())
+        op = E.Operand(gd, tuple(cd.shape), pro=L.PRO_BNACT_BWD if pro == 'bnact_bwd' else L.PRO_BNBWD, x2=cd, **kw)
+        rd = nhwc(skip).cuda().bfloat16() if res else None
+        xd = nhwc(xb).cuda().bfloat16()
+        b_slope = slope.cuda() if bnb == 'act' else None
+        out = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_TRUNK', sw)
+            r = E.conv_dgrad(p, op, res=rd, bnb=None if bnb is None else (xd, kb, b_slope))
+            out[sw] = r if bnb is not None else (r, None)
+        assert maxrel(nchw(out['1'][0].float()), out_ref) < BF16_TOL
+        assert maxrel(out['1'][0].float(), out['0'][0].float()) < 6e-3
+        if bnb is not None:
+            assert out['1'][1].shape[0] <= min(out['0'][1].shape[0], 512)
+            s1, s0 = out['1'][1].double().sum(0), out['0'][1].double().sum(0)
+            assert maxrel(s1[:128], s0[:128]) < 2e-3                       # sum(g), sum(g * xhat) per channel
+            if bnb == 'act':
+                assert abs(float(s1[128] - s0[128])) <= 2e-3 * max(1.0, abs(float(s0[128])))
+            fused = E.bn_backward(out['1'][0], xd, kb, gamma.cuda(), slope=b_slope, part=out['1'][1])
+            plain = E.bn_backward(out['1'][0], xd, kb, gamma.cuda(), slope=b_slope)
+            for a, b in zip(fused, plain):
+                if a is not None:
+                    assert maxrel(a, b) < 5e-3
+    finally:
+        E.set_precision('fp32')
