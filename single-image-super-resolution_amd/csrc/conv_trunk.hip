@@ -400,9 +400,13 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
         int n, ty, tx;
         tile_coords(T, n, ty, tx);
         sok = 0;
+        // (opaque copies: the per-item index arithmetic is recomputed per tile instead of being hoisted out of the tile
+        // loop into registers that the 144 weight registers leave no room for)
+        int pt_ = ptid, ln_ = lane;
+        asm volatile("" : "+v"(pt_), "+v"(ln_));
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
-            const int idx = ptid + k * 256, px = idx >> 3;
+            const int idx = pt_ + k * 256, px = idx >> 3;
             const int py = px / TK_IW, pxx = px - py * TK_IW;
             const int iy = ty * TK_TH - 1 + py, ix = tx * TK_TW - 1 + pxx;
             const bool ok = px < TK_NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
@@ -419,8 +423,8 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
             const int pw = wave & 3;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int c = 4 * pw + k, m = 8 * c + (lane >> 3);                  // tile pixel m = row (m >> 4), col (m & 15)
-                const int o = (lane & 7) ^ (2 * (m & 3));
+                const int c = 4 * pw + k, m = 8 * c + (ln_ >> 3);                   // tile pixel m = row (m >> 4), col (m & 15)
+                const int o = (ln_ & 7) ^ (2 * (m & 3));
                 const unsigned voff = (unsigned)(((n * a.H + ty * TK_TH + (m >> 4)) * a.W + tx * TK_TW + (m & 15)) * 128 + o * 16);
                 if (has_r)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(q1, (__attribute__((address_space(3))) void*)(ir + c * 1024),
@@ -433,18 +437,46 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
     };
     auto commit = [&](int b) {
         unsigned char* buf = lds + b * (TK_NPIX * TK_PSB);
+        // BNACT_BWD in two passes so that at most 24 constant registers are live at a time: first the sign of the
+        // re-derived pre-activation (s, t) of every element as a bit mask, then the affine part (a, b, d)
+        unsigned zm[2] = {0u, 0u};
+        int pt_ = ptid;
+        asm volatile("" : "+v"(pt_));
+        const int oct = pt_ & 7;
+        if (PRO == SISR_PRO_BNACT_BWD) {
+            const f32x8 ks = *reinterpret_cast<const f32x8*>(kst + 192 + oct * 8), kt = *reinterpret_cast<const f32x8*>(kst + 256 + oct * 8);
+#pragma unroll
+            for (int k = 0; k < TK_ITEMS; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float b0 = __uint_as_float(sb[k][j] << 16), b1 = __uint_as_float(sb[k][j] & 0xFFFF0000u);
+                    const unsigned p0 = ks[2 * j] * b0 + kt[2 * j] > 0.f ? 1u : 0u, p1 = ks[2 * j + 1] * b1 + kt[2 * j + 1] > 0.f ? 1u : 0u;
+                    zm[k >> 2] |= (p0 | (p1 << 1)) << ((k & 3) * 8 + 2 * j);
+                }
+        }
         const f32x8 ka = *reinterpret_cast<const f32x8*>(kst + oct * 8), kb = *reinterpret_cast<const f32x8*>(kst + 64 + oct * 8),
                     kd = *reinterpret_cast<const f32x8*>(kst + 128 + oct * 8);
-        f32x8 ks = ka, kt = ka;
-        if (PRO == SISR_PRO_BNACT_BWD) {
-            ks = *reinterpret_cast<const f32x8*>(kst + 192 + oct * 8);
-            kt = *reinterpret_cast<const f32x8*>(kst + 256 + oct * 8);
-        }
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
-            const int idx = ptid + k * 256, px = idx >> 3;
-            const u32x4 v = trunk_apply8<PRO>(sa[k], sb[k], ka, kb, kd, ks, kt, slope, (sok >> k) & 1u);
-            if (px < TK_NPIX) *reinterpret_cast<u32x4*>(buf + px * TK_PSB + oct * 16) = v;
+            const int idx = pt_ + k * 256, px = idx >> 3;
+            const bool ok = (sok >> k) & 1u;
+            const unsigned mk = zm[k >> 2] >> ((k & 3) * 8);
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a0 = __uint_as_float(sa[k][j] << 16), a1 = __uint_as_float(sa[k][j] & 0xFFFF0000u);
+                const float b0 = __uint_as_float(sb[k][j] << 16), b1 = __uint_as_float(sb[k][j] & 0xFFFF0000u);
+                float g0 = a0, g1 = a1;
+                if (PRO == SISR_PRO_BNACT_BWD) {
+                    g0 = (mk >> (2 * j)) & 1u ? a0 : slope * a0;
+                    g1 = (mk >> (2 * j + 1)) & 1u ? a1 : slope * a1;
+                }
+                const float r0 = ka[2 * j] * g0 + kb[2 * j] * b0 + kd[2 * j];
+                const float r1 = ka[2 * j + 1] * g1 + kb[2 * j + 1] * b1 + kd[2 * j + 1];
+                // f(0) != 0: the halo must be zero AFTER the transform
+                o[j] = ok ? (f32_to_bf16_bits(r0) | (f32_to_bf16_bits(r1) << 16)) : 0u;
+            }
+            if (px < TK_NPIX) *reinterpret_cast<u32x4*>(buf + px * TK_PSB + oct * 16) = o;
         }
     };
     __bf16* my_out = out_img + (wave & 3) * (32 * TK_YS);
