@@ -150,6 +150,12 @@ int sisr_conv2d_trunk_eligible(const SisrConvDesc *d);
 int sisr_conv2d_bf16_parts(const SisrConvDesc *d);
 int sisr_wgrad_plan_bf16(SisrWgradDesc *d, int32_t max_pixel_blocks);
 int sisr_conv2d_wgrad_bf16(const SisrWgradDesc *d, void *stream);
+/* The trunk geometry with bf16 NHWC operands (x prologue NONE / ACT / AFFINE_ACT, gradient prologue BNBWD /
+ * BNACT_BWD) runs on the persistent kernel of wgrad_trunk.hip behind sisr_conv2d_wgrad_bf16: one slab per workgroup,
+ * whatever the plan's n_slabs says.  sisr_wgrad_bf16_slabs(d) = slabs the launch of a fully filled descriptor writes
+ * -- size `slab` (rows of slab_stride floats) and the reduction with it. */
+int sisr_wgrad_trunk_eligible(const SisrWgradDesc *d);
+int sisr_wgrad_bf16_slabs(const SisrWgradDesc *d);
 int sisr_conv2d_wgrad_f32(const SisrWgradDesc *d, void *stream);
 /* out[i] = sum_s slab[s][i], i < elems (also used for the bias slabs) */
 int sisr_slab_reduce_f32(const float *slab, float *out, int32_t n_slabs, int64_t elems, void *stream);

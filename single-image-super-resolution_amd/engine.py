@@ -461,9 +461,10 @@ def conv_wgrad(prep, x_op, dy_op):
                 'sisr_nchw_grad_to_nhwc4')
         dy_op = Operand.plain(g4)
     stride = g.slab_stride
-    slab = torch.empty((g.n_slabs, stride), dtype=torch.float32, device=dev)
     x_op.fill(g)
     dy_op.fill(g, g=True)
+    n_slabs = lib.sisr_wgrad_bf16_slabs(C.byref(g)) if prep.kinds[2] else g.n_slabs
+    slab = torch.empty((n_slabs, stride), dtype=torch.float32, device=dev)
     g.slab = slab.data_ptr()
     g.bias_slab = slab.data_ptr() + 4 * g.slab_elems
     if prep.kinds[2]:
@@ -471,7 +472,7 @@ def conv_wgrad(prep, x_op, dy_op):
     else:
         L.check(lib.sisr_conv2d_wgrad_f32(C.byref(g), _stream()), 'sisr_conv2d_wgrad_f32')
     red = torch.empty((stride,), dtype=torch.float32, device=dev)
-    L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), red.data_ptr(), g.n_slabs, stride, _stream()),
+    L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), red.data_ptr(), n_slabs, stride, _stream()),
             'sisr_slab_reduce_f32')
     return red
 

@@ -470,3 +470,65 @@ def test_trunk_kernel_data_gradient_role(E, L, shape, pro, res, bnb, monkeypatch
                     assert maxrel(a, b) < 5e-3
     finally:
         E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('xpro,gpro', [('none', 'bnbwd'), ('act', 'bnact_bwd'), ('affine_act', 'bnbwd'), ('affine_act', 'bnact_bwd')])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 48), (1, 96, 96)])
+def test_trunk_kernel_weight_gradient_role(E, L, shape, xpro, gpro, monkeypatch):
+    """wgrad_trunk.hip (persistent, the whole 64 x 576 gradient in accumulators, one slab per workgroup) against the
+    generic bf16 weight-gradient kernel on the same lazy operands and against autograd on the prologues written out in
+    fp32: packed gradient, un-packed weight gradient, bias gradient"""
+    n, h, w = shape
+    monkeypatch.setenv('SISR_STORAGE', 'bf16')
+    bf = lambda t: t.bfloat16().float()
+    bc = lambda v: v[None, :, None, None]
+    x = bf(_rand((n, 64, h, w), 91) * 2.0)
+    g_in, c = bf(_rand((n, 64, h, w), 92)), bf(_rand((n, 64, h, w), 93) * 2.0)
+    wt = _rand((64, 64, 3, 3), 94, (1.0 / 576) ** 0.5)
+    b = _rand((64,), 95, 0.1)
+    sc, sh = _rand((64,), 96) * 0.5 + 1.0, _rand((64,), 97) * 0.3
+    qa, qb, qd = _rand((64,), 98) * 0.3 + 1.0, _rand((64,), 99) * 0.2, _rand((64,), 100) * 0.1
+    ks, kt = _rand((64,), 101) * 0.5 + 1.0, _rand((64,), 102) * 0.3
+    slope = torch.tensor([0.2])
+    xin = x
+    if xpro == 'act':
+        xin = F.leaky_relu(x, 0.2)
+    elif xpro == 'affine_act':
+        xin = F.leaky_relu(x * bc(sc) + bc(sh), 0.2)
+    gg = g_in
+    if gpro == 'bnact_bwd':
+        gg = torch.where(bc(ks) * c + bc(kt) > 0, g_in, 0.2 * g_in)
+    dy_ref = bc(qa) * gg + bc(qb) * c + bc(qd)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (F.conv2d(xin, wr, br, padding=1) * dy_ref).sum().backward()
+    E.set_precision('bf16')
+    try:
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 64, 3, 1, 1))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        xd = nhwc(x).cuda().bfloat16()
+        if xpro == 'none':
+            x_op = E.Operand.plain(xd)
+        elif xpro == 'act':
+            x_op = E.Operand.act(xd, slope.cuda())
+        else:
+            x_op = E.Operand.affine_act(xd, sc.cuda(), sh.cuda(), slope.cuda())
+        gd, cd = nhwc(g_in).cuda().bfloat16(), nhwc(c).cuda().bfloat16()
+        kw = dict(pa=qa.cuda(), pb=qb.cuda(), pd=qd.cuda())
+        if gpro == 'bnact_bwd':
+            kw.update(ps=ks.cuda(), pt=kt.cuda(), slope=slope.cuda())
+        dy_op = E.Operand(gd, tuple(cd.shape), pro=L.PRO_BNACT_BWD if gpro == 'bnact_bwd' else L.PRO_BNBWD, x2=cd, **kw)
+        red = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_TRUNK_WGRAD', sw)
+            red[sw] = E.conv_wgrad(p, x_op, dy_op)
+        assert maxrel(red['1'], red['0']) < 2e-3                     # same products, different fp32 summation order
+        wg = E.WeightGradBatch()
+        wg.add(p, red['1'])
+        gw, gb = wg.run()[id(ref)]
+        assert maxrel(gw, wr.grad) < BF16_TOL, 'wgrad'
+        assert maxrel(gb, br.grad) < BF16_TOL, 'bias grad'
+        # deterministic: a second launch reproduces the first bit for bit
+        monkeypatch.setenv('SISR_TRUNK_WGRAD', '1')
+        assert torch.equal(E.conv_wgrad(p, x_op, dy_op), red['1'])
+    finally:
+        E.set_precision('fp32')
