@@ -197,25 +197,37 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     __bf16* my_out = out_img + (wave & 3) * (32 * TK_YS);
     const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
 
-    int T = blockIdx.x;
-    if (!consumer && T < a.total) {
-        issue(T);
-        commit(lds);
-    }
-    TT(2);
-    __syncthreads();
-    int cur = 0;
-    int it = 0;
-    for (; T < a.total; T += gridDim.x, cur ^= 1, ++it) {
-        const int Tn = T + gridDim.x;
-        TT(4 + 6 * it);
-        if (!consumer) {
-            // ---- producer: the next tile, into the other buffer ---------------------------------------------------------
+    // Two role-specific tile loops with matching barrier counts (a barrier only counts arriving waves).  Written as ONE
+    // loop with a role branch inside, the register allocator carries the consumers' 144 weight registers through the
+    // producers' code (and the producers' staging registers through the consumers').
+    if (!consumer) {
+        // ---- producers: tile T + 1 into the other buffer while the consumers work on tile T ------------------------------
+        int T = blockIdx.x;
+        if (T < a.total) {
+            issue(T);
+            commit(lds);
+        }
+        TT(2);
+        __syncthreads();
+        int cur = 0, it = 0;
+        for (; T < a.total; T += gridDim.x, cur ^= 1, ++it) {
+            const int Tn = T + gridDim.x;
+            TT(4 + 6 * it);
             if (Tn < a.total) {
                 issue(Tn);
                 commit(lds + (cur ^ 1) * (TK_NPIX * TK_PSB));
             }
-        } else {
+            TT(8 + 6 * it);
+            __syncthreads();
+            TT(9 + 6 * it);
+        }
+    } else {
+        TT(2);
+        __syncthreads();
+        int cur = 0, it = 0;
+        for (int T = blockIdx.x; T < a.total; T += gridDim.x, cur ^= 1, ++it) {
+            TT(4 + 6 * it);
+            {
             // ---- consumer: MFMA phase (2 sub-tiles x 9 taps x 4 K-steps; every A address is base + immediate) ... -------
             f32x16 acc[2];
 #pragma unroll
@@ -282,10 +294,11 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
                                                (32 * h + 8 * grp) * 2);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v8), ry, vo, 0, 0);
             }
+            }
+            TT(8 + 6 * it);
+            __syncthreads();      // the next tile's image is complete; the consumers have finished reading this one
+            TT(9 + 6 * it);
         }
-        TT(8 + 6 * it);
-        __syncthreads();          // the next tile's image is complete; the consumers have finished reading this one
-        TT(9 + 6 * it);
     }
     TT(3);
 
@@ -482,21 +495,28 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
     __bf16* my_out = out_img + (wave & 3) * (32 * TK_YS);
     const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
 
-    int T = blockIdx.x;
-    if (!consumer && T < a.total) {
-        issue(T, 0);
-        commit(0);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (; T < a.total; T += gridDim.x, cur ^= 1) {
-        const int Tn = T + gridDim.x;
-        if (!consumer) {
+    // role-specific tile loops with matching barrier counts (see the forward kernel)
+    if (!consumer) {
+        int T = blockIdx.x;
+        if (T < a.total) {
+            issue(T, 0);
+            commit(0);
+        }
+        __syncthreads();
+        int cur = 0;
+        for (; T < a.total; T += gridDim.x, cur ^= 1) {
+            const int Tn = T + gridDim.x;
             if (Tn < a.total) {
                 issue(Tn, cur ^ 1);
                 commit(cur ^ 1);
             }
-        } else {
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        int cur = 0;
+        for (int T = blockIdx.x; T < a.total; T += gridDim.x, cur ^= 1) {
+            {
             f32x16 acc[2];
 #pragma unroll
             for (int ms = 0; ms < 2; ++ms)
@@ -568,8 +588,9 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
                                                (32 * h + 8 * grp) * 2);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v8), ry, vo, 0, 0);
             }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // ---- one row of BatchNorm-backward partial sums per workgroup ----------------------------------------------------
