@@ -38,17 +38,23 @@
 // phase timeline, developer build only (make trace; tools/trace_trunk.py): thread 0 stamps the 100 MHz wall clock
 #ifdef SISR_CONV_TRACE
 #define TT_WG 512
-#define TT_SLOTS 64
+#define TT_SLOTS 128
 __device__ unsigned long long sisr_ttrace_buf[TT_WG * TT_SLOTS];
 #define TT(k)                                                                                                   \
     do {                                                                                                        \
         if (threadIdx.x == 0 && blockIdx.x < TT_WG && (k) < TT_SLOTS) sisr_ttrace_buf[blockIdx.x * TT_SLOTS + (k)] = wall_clock64(); \
+    } while (0)
+// producer timeline: thread 256 (first producer wave), slots 64 ..
+#define TTP(k)                                                                                                  \
+    do {                                                                                                        \
+        if (threadIdx.x == 256 && blockIdx.x < TT_WG && 64 + (k) < TT_SLOTS) sisr_ttrace_buf[blockIdx.x * TT_SLOTS + 64 + (k)] = wall_clock64(); \
     } while (0)
 extern "C" int sisr_ttrace_read(void* dst, int n_u64) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sisr_ttrace_buf), (size_t)n_u64 * 8, 0, hipMemcpyDeviceToHost);
 }
 #else
 #define TT(k)
+#define TTP(k)
 #endif
 
 struct TrunkArgs {
@@ -115,6 +121,9 @@ __device__ __forceinline__ u32x4 trunk_apply8(u32x4 a, u32x4 b, const f32x8& ka,
 // SIMD (the dispatcher deals a workgroup's waves over the SIMDs cyclically), so each SIMD overlaps one matrix-heavy
 // and one memory / VALU-heavy wave.  One workgroup barrier per tile.
 #define TK_THREADS 512
+#ifndef TK_PF
+#define TK_PF 3                           // A-fragment prefetch distance of the consumers' MFMA loop, in steps of 2 MFMAs
+#endif
 template <int PRO>
 __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const TrunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -149,7 +158,9 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     unsigned sok = 0;
 
     TT(0);
-    if (consumer) {
+    // (role state is set up INSIDE the role branches below: set up ahead of the split, every register of both roles
+    // meets in one merge block and the allocator spills weights at load time)
+    auto init_consumer = [&]() {
         const __amdgpu_buffer_rsrc_t wrs = bf_rsrc(a.wpk, 2u * 64u * 9u * 32u * 2u);
         const int co = 32 * h + l31;
 #pragma unroll
@@ -163,18 +174,23 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) a_base[ms] = ((4 * g + 2 * ms + (l31 >> 4)) * TK_IW + (l31 & 15)) * TK_PSB + kk * 16;
         bv = a.bias != nullptr ? a.bias[32 * h + l31] : 0.f;
-    } else {
+    };
+    auto init_producer = [&]() {
         slope = a.slope_p ? a.slope_p[0] : a.slope;
         if (PRO == SISR_PRO_AFFINE_ACT) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { ka[j] = a.pa[oct * 8 + j]; kd[j] = a.pd[oct * 8 + j]; }
         }
-    }
-    auto issue = [&](int T) {
+    };
+    // two staging register sets: the loads of tile T + 2 are in flight while tile T + 1 is transformed and written to
+    // LDS, so the producers never sit out a full memory latency (they are the critical path otherwise)
+    u32x4 sreg2[TK_ITEMS];
+    unsigned sok2 = 0;
+    auto issue = [&](int T, u32x4 (&sr)[TK_ITEMS], unsigned& okm) {
         const __amdgpu_buffer_rsrc_t rx = bf_rsrc(a.x1, xbytes);
         int n, ty, tx;
         tile_coords(T, n, ty, tx);
-        sok = 0;
+        okm = 0;
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
             const int idx = ptid + k * 256, px = idx >> 3;
@@ -182,15 +198,15 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
             const int iy = ty * TK_TH - 1 + py, ix = tx * TK_TW - 1 + pxx;
             const bool ok = px < TK_NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const unsigned voff = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * 128 + oct * 16) : 0x80000000u;
-            sreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0);
-            sok |= ok ? (1u << k) : 0u;
+            sr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0);
+            okm |= ok ? (1u << k) : 0u;
         }
     };
-    auto commit = [&](unsigned char* buf) {
+    auto commit = [&](unsigned char* buf, const u32x4 (&sr)[TK_ITEMS], unsigned okm) {
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
             const int idx = ptid + k * 256, px = idx >> 3;
-            const u32x4 v = trunk_apply8<PRO>(sreg[k], sreg[k], ka, ka, kd, ka, ka, slope, (sok >> k) & 1u);
+            const u32x4 v = trunk_apply8<PRO>(sr[k], sr[k], ka, ka, kd, ka, ka, slope, (okm >> k) & 1u);
             if (px < TK_NPIX) *reinterpret_cast<u32x4*>(buf + px * TK_PSB + oct * 16) = v;
         }
     };
@@ -202,26 +218,35 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     // producers' code (and the producers' staging registers through the consumers').
     if (!consumer) {
         // ---- producers: tile T + 1 into the other buffer while the consumers work on tile T ------------------------------
+        init_producer();
         int T = blockIdx.x;
         if (T < a.total) {
-            issue(T);
-            commit(lds);
+            issue(T, sreg, sok);
+            if (T + (int)gridDim.x < a.total) issue(T + gridDim.x, sreg2, sok2);
+            commit(lds, sreg, sok);
         }
-        TT(2);
+        TTP(2);
         __syncthreads();
         int cur = 0, it = 0;
         for (; T < a.total; T += gridDim.x, cur ^= 1, ++it) {
-            const int Tn = T + gridDim.x;
-            TT(4 + 6 * it);
-            if (Tn < a.total) {
-                issue(Tn);
-                commit(lds + (cur ^ 1) * (TK_NPIX * TK_PSB));
+            const int Tn = T + gridDim.x, Tnn = Tn + gridDim.x;
+            TTP(4 + 6 * it);
+            // tile Tn is in the set filled one iteration ago (sreg2 on even iterations); tile Tnn goes into the other one
+            if (it & 1) {
+                if (Tnn < a.total) issue(Tnn, sreg2, sok2);
+                TTP(5 + 6 * it);
+                if (Tn < a.total) commit(lds + (cur ^ 1) * (TK_NPIX * TK_PSB), sreg, sok);
+            } else {
+                if (Tnn < a.total) issue(Tnn, sreg, sok);
+                TTP(5 + 6 * it);
+                if (Tn < a.total) commit(lds + (cur ^ 1) * (TK_NPIX * TK_PSB), sreg2, sok2);
             }
-            TT(8 + 6 * it);
+            TTP(8 + 6 * it);
             __syncthreads();
-            TT(9 + 6 * it);
+            TTP(9 + 6 * it);
         }
     } else {
+        init_consumer();
         TT(2);
         __syncthreads();
         int cur = 0, it = 0;
@@ -235,17 +260,26 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[ms][i] = 0.f;
             const unsigned char* ib = lds + cur * (TK_NPIX * TK_PSB);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
+            // software pipeline: the A fragments of step s + TK_PF are requested before the two MFMAs of step s
+            // (step = tap t, K slice j; left to itself the compiler keeps one step of reads in flight, ~64 cycles of cover)
+            bf16x8 af[36][2];
+            auto fetch = [&](int st) {
+                const int t = st >> 2, j = st & 3;
                 const int toff = ((t / 3) * TK_IW + (t % 3)) * TK_PSB;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int ms = 0; ms < 2; ++ms) af[st][ms] = *reinterpret_cast<const bf16x8*>(ib + a_base[ms] + toff + j * 32);
+            };
 #pragma unroll
-                    for (int ms = 0; ms < 2; ++ms) {
-                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(ib + a_base[ms] + toff + j * 32);
-                        acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bw[t][j], acc[ms], 0, 0, 0);
-                    }
-                }
+            for (int st = 0; st < TK_PF; ++st) fetch(st);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TK_PF, 0);
+#pragma unroll
+            for (int st = 0; st < 36; ++st) {
+                if (st + TK_PF < 36) fetch(st + TK_PF);
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms)
+                    acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st][ms], bw[st >> 2][st & 3], acc[ms], 0, 0, 0);
+                if (st + TK_PF < 36) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
             TT(6 + 6 * it);
             // ---- ... and epilogue: bias, statistics, bf16, transposed store -------------------------------------------------
@@ -353,7 +387,6 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __bf16* out_img = reinterpret_cast<__bf16*>(lds + 2 * TK_NPIX * TK_PSB);            // [4 waves][32][TK_YS]
     float* red = reinterpret_cast<float*>(lds + 2 * TK_NPIX * TK_PSB + 4 * 32 * TK_YS * 2);   // [4 waves][32][2] + [4]
-    float* kst = red + TK_KOFF;                                                          // a, b, d, s, t: [5][64]
     unsigned char* img0 = lds + 2 * TK_NPIX * TK_PSB + 4 * 32 * TK_YS * 2 + TK_RED_BYTES;   // [2 buffers][res, bnb_x][TK_IMG]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -381,15 +414,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
     u32x4 sa[TK_ITEMS], sb[TK_ITEMS];
     unsigned sok = 0;
 
-    // the per-channel prologue constants live in LDS (re-read at every commit: 40 registers the producers would
-    // otherwise hold across the tile loop, on top of the consumers' 144 weight registers)
-    if (tid < 64) {
-        kst[tid] = a.pa[tid]; kst[64 + tid] = a.pb[tid]; kst[128 + tid] = a.pd[tid];
-        kst[192 + tid] = PRO == SISR_PRO_BNACT_BWD ? a.ps[tid] : 0.f;
-        kst[256 + tid] = PRO == SISR_PRO_BNACT_BWD ? a.pt[tid] : 0.f;
-    }
-    __syncthreads();
-    if (consumer) {
+    auto init_consumer = [&]() {
         const __amdgpu_buffer_rsrc_t wrs = bf_rsrc(a.wpk, 2u * 64u * 9u * 32u * 2u);
         const int co = 32 * h + l31;
 #pragma unroll
@@ -405,18 +430,19 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
             b_sc = a.bnb_scale[co]; b_sf = a.bnb_shift[co]; b_mu = a.bnb_mean[co]; b_is = a.bnb_invstd[co];
             b_slope = a.bnb_slope_p ? a.bnb_slope_p[0] : a.bnb_slope;
         }
-    } else {
-        slope = a.slope_p ? a.slope_p[0] : a.slope;
-    }
-    auto issue = [&](int T, int b) {
+    };
+    // two staging register sets: the loads of tile T + 2 are in flight while tile T + 1 is transformed and written to LDS
+    u32x4 sa2[TK_ITEMS], sb2[TK_ITEMS];
+    unsigned sok2 = 0;
+    auto issue = [&](int T, u32x4 (&ra)[TK_ITEMS], u32x4 (&rb)[TK_ITEMS], unsigned& okm) {
         const __amdgpu_buffer_rsrc_t r1 = bf_rsrc(a.x1, xbytes), r2 = bf_rsrc(a.x2, xbytes);
         int n, ty, tx;
         tile_coords(T, n, ty, tx);
-        sok = 0;
+        okm = 0;
         // (opaque copies: the per-item index arithmetic is recomputed per tile instead of being hoisted out of the tile
-        // loop into registers that the 144 weight registers leave no room for)
-        int pt_ = ptid, ln_ = lane;
-        asm volatile("" : "+v"(pt_), "+v"(ln_));
+        // loop into registers)
+        int pt_ = ptid;
+        asm volatile("" : "+v"(pt_));
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
             const int idx = pt_ + k * 256, px = idx >> 3;
@@ -424,72 +450,49 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
             const int iy = ty * TK_TH - 1 + py, ix = tx * TK_TW - 1 + pxx;
             const bool ok = px < TK_NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const unsigned voff = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * 128 + oct * 16) : 0x80000000u;
-            sa[k] = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0);
-            sb[k] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0);
-            sok |= ok ? (1u << k) : 0u;
-        }
-        if (has_r || has_x) {
-            // the tile's own 128 pixels x 8 octets, LDS-direct: producer wave pw lays down 1 KB chunks 4 pw + k (8 pixels
-            // each); lane = (pixel lane >> 3, slot lane & 7) fetches octet slot ^ 2 (pixel & 3)
-            const __amdgpu_buffer_rsrc_t q1 = bf_rsrc(has_r ? a.res : a.bnb_x, xbytes), q2 = bf_rsrc(has_x ? a.bnb_x : a.res, xbytes);
-            unsigned char* ir = img0 + b * (2 * TK_IMG);
-            const int pw = wave & 3;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = 4 * pw + k, m = 8 * c + (ln_ >> 3);                   // tile pixel m = row (m >> 4), col (m & 15)
-                const int o = (ln_ & 7) ^ (2 * (m & 3));
-                const unsigned voff = (unsigned)(((n * a.H + ty * TK_TH + (m >> 4)) * a.W + tx * TK_TW + (m & 15)) * 128 + o * 16);
-                if (has_r)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(q1, (__attribute__((address_space(3))) void*)(ir + c * 1024),
-                                                             16, voff, 0, 0, 0);
-                if (has_x)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(q2, (__attribute__((address_space(3))) void*)(ir + TK_IMG + c * 1024),
-                                                             16, voff, 0, 0, 0);
-            }
+            ra[k] = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0);
+            rb[k] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0);
+            okm |= ok ? (1u << k) : 0u;
         }
     };
-    auto commit = [&](int b) {
+    // the tile's own 128 pixels x 8 octets of the residual and of the BatchNorm input, LDS-direct into image buffer b:
+    // producer wave pw lays down 1 KB chunks 4 pw + k (8 pixels each); lane = (pixel lane >> 3, slot lane & 7) fetches
+    // octet slot ^ 2 (pixel & 3).  Issued for tile T + 1 only (the images are double-buffered, not triple-buffered).
+    auto issue_images = [&](int T, int b) {
+        if (!(has_r || has_x)) return;
+        int n, ty, tx;
+        tile_coords(T, n, ty, tx);
+        int ln_ = lane;
+        asm volatile("" : "+v"(ln_));
+        const __amdgpu_buffer_rsrc_t q1 = bf_rsrc(has_r ? a.res : a.bnb_x, xbytes), q2 = bf_rsrc(has_x ? a.bnb_x : a.res, xbytes);
+        unsigned char* ir = img0 + b * (2 * TK_IMG);
+        const int pw = wave & 3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * pw + k, m = 8 * c + (ln_ >> 3);                   // tile pixel m = row (m >> 4), col (m & 15)
+            const int o = (ln_ & 7) ^ (2 * (m & 3));
+            const unsigned voff = (unsigned)(((n * a.H + ty * TK_TH + (m >> 4)) * a.W + tx * TK_TW + (m & 15)) * 128 + o * 16);
+            if (has_r)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(q1, (__attribute__((address_space(3))) void*)(ir + c * 1024),
+                                                         16, voff, 0, 0, 0);
+            if (has_x)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(q2, (__attribute__((address_space(3))) void*)(ir + TK_IMG + c * 1024),
+                                                         16, voff, 0, 0, 0);
+        }
+    };
+    // per-channel prologue constants of this thread's octet, in registers for the whole tile loop (the producers' loop has
+    // its own register budget, and a producer that reads LDS would wait for its LDS-direct loads first)
+    const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x8 ka = zero8, kb = zero8, kd = zero8, ks = zero8, kt = zero8;
+    auto commit = [&](int b, const u32x4 (&ra)[TK_ITEMS], const u32x4 (&rb)[TK_ITEMS], unsigned okm) {
         unsigned char* buf = lds + b * (TK_NPIX * TK_PSB);
-        // BNACT_BWD in two passes so that at most 24 constant registers are live at a time: first the sign of the
-        // re-derived pre-activation (s, t) of every element as a bit mask, then the affine part (a, b, d)
-        unsigned zm[2] = {0u, 0u};
         int pt_ = ptid;
         asm volatile("" : "+v"(pt_));
-        const int oct = pt_ & 7;
-        if (PRO == SISR_PRO_BNACT_BWD) {
-            const f32x8 ks = *reinterpret_cast<const f32x8*>(kst + 192 + oct * 8), kt = *reinterpret_cast<const f32x8*>(kst + 256 + oct * 8);
-#pragma unroll
-            for (int k = 0; k < TK_ITEMS; ++k)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float b0 = __uint_as_float(sb[k][j] << 16), b1 = __uint_as_float(sb[k][j] & 0xFFFF0000u);
-                    const unsigned p0 = ks[2 * j] * b0 + kt[2 * j] > 0.f ? 1u : 0u, p1 = ks[2 * j + 1] * b1 + kt[2 * j + 1] > 0.f ? 1u : 0u;
-                    zm[k >> 2] |= (p0 | (p1 << 1)) << ((k & 3) * 8 + 2 * j);
-                }
-        }
-        const f32x8 ka = *reinterpret_cast<const f32x8*>(kst + oct * 8), kb = *reinterpret_cast<const f32x8*>(kst + 64 + oct * 8),
-                    kd = *reinterpret_cast<const f32x8*>(kst + 128 + oct * 8);
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
             const int idx = pt_ + k * 256, px = idx >> 3;
-            const bool ok = (sok >> k) & 1u;
-            const unsigned mk = zm[k >> 2] >> ((k & 3) * 8);
-            u32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a0 = __uint_as_float(sa[k][j] << 16), a1 = __uint_as_float(sa[k][j] & 0xFFFF0000u);
-                const float b0 = __uint_as_float(sb[k][j] << 16), b1 = __uint_as_float(sb[k][j] & 0xFFFF0000u);
-                float g0 = a0, g1 = a1;
-                if (PRO == SISR_PRO_BNACT_BWD) {
-                    g0 = (mk >> (2 * j)) & 1u ? a0 : slope * a0;
-                    g1 = (mk >> (2 * j + 1)) & 1u ? a1 : slope * a1;
-                }
-                const float r0 = ka[2 * j] * g0 + kb[2 * j] * b0 + kd[2 * j];
-                const float r1 = ka[2 * j + 1] * g1 + kb[2 * j + 1] * b1 + kd[2 * j + 1];
-                // f(0) != 0: the halo must be zero AFTER the transform
-                o[j] = ok ? (f32_to_bf16_bits(r0) | (f32_to_bf16_bits(r1) << 16)) : 0u;
-            }
-            if (px < TK_NPIX) *reinterpret_cast<u32x4*>(buf + px * TK_PSB + oct * 16) = o;
+            const u32x4 v = trunk_apply8<PRO>(ra[k], rb[k], ka, kb, kd, ks, kt, slope, (okm >> k) & 1u);
+            if (px < TK_NPIX) *reinterpret_cast<u32x4*>(buf + px * TK_PSB + (pt_ & 7) * 16) = v;
         }
     };
     __bf16* my_out = out_img + (wave & 3) * (32 * TK_YS);
@@ -497,22 +500,37 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
 
     // role-specific tile loops with matching barrier counts (see the forward kernel)
     if (!consumer) {
+        slope = a.slope_p ? a.slope_p[0] : a.slope;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ka[j] = a.pa[oct * 8 + j]; kb[j] = a.pb[oct * 8 + j]; kd[j] = a.pd[oct * 8 + j];
+            if (PRO == SISR_PRO_BNACT_BWD) { ks[j] = a.ps[oct * 8 + j]; kt[j] = a.pt[oct * 8 + j]; }
+        }
         int T = blockIdx.x;
         if (T < a.total) {
-            issue(T, 0);
-            commit(0);
+            issue_images(T, 0);
+            issue(T, sa, sb, sok);
+            if (T + (int)gridDim.x < a.total) issue(T + gridDim.x, sa2, sb2, sok2);
+            commit(0, sa, sb, sok);
         }
         __syncthreads();
-        int cur = 0;
-        for (; T < a.total; T += gridDim.x, cur ^= 1) {
-            const int Tn = T + gridDim.x;
-            if (Tn < a.total) {
-                issue(Tn, cur ^ 1);
-                commit(cur ^ 1);
+        int cur = 0, it = 0;
+        for (; T < a.total; T += gridDim.x, cur ^= 1, ++it) {
+            const int Tn = T + gridDim.x, Tnn = Tn + gridDim.x;
+            // register loads of tile Tnn and LDS-direct loads of tile Tn go out back to back, then tile Tn is committed from
+            // the register set filled one iteration ago (sa2 / sb2 on even iterations) while they fly.  The barrier's fence
+            // drains them all (it must, for the LDS-direct ones), which costs little: they were issued together.
+            if (it & 1) {
+                if (Tnn < a.total) issue(Tnn, sa2, sb2, sok2);
+                if (Tn < a.total) { issue_images(Tn, cur ^ 1); commit(cur ^ 1, sa, sb, sok); }
+            } else {
+                if (Tnn < a.total) issue(Tnn, sa, sb, sok);
+                if (Tn < a.total) { issue_images(Tn, cur ^ 1); commit(cur ^ 1, sa2, sb2, sok2); }
             }
             __syncthreads();
         }
     } else {
+        init_consumer();
         __syncthreads();
         int cur = 0;
         for (int T = blockIdx.x; T < a.total; T += gridDim.x, cur ^= 1) {
@@ -523,17 +541,26 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[ms][i] = 0.f;
             const unsigned char* ib = lds + cur * (TK_NPIX * TK_PSB);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
+            // software pipeline: the A fragments of step s + TK_PF are requested before the two MFMAs of step s
+            // (step = tap t, K slice j; left to itself the compiler keeps one step of reads in flight, ~64 cycles of cover)
+            bf16x8 af[36][2];
+            auto fetch = [&](int st) {
+                const int t = st >> 2, j = st & 3;
                 const int toff = ((t / 3) * TK_IW + (t % 3)) * TK_PSB;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int ms = 0; ms < 2; ++ms) af[st][ms] = *reinterpret_cast<const bf16x8*>(ib + a_base[ms] + toff + j * 32);
+            };
 #pragma unroll
-                    for (int ms = 0; ms < 2; ++ms) {
-                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(ib + a_base[ms] + toff + j * 32);
-                        acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bw[t][j], acc[ms], 0, 0, 0);
-                    }
-                }
+            for (int st = 0; st < TK_PF; ++st) fetch(st);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TK_PF, 0);
+#pragma unroll
+            for (int st = 0; st < 36; ++st) {
+                if (st + TK_PF < 36) fetch(st + TK_PF);
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms)
+                    acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st][ms], bw[st >> 2][st & 3], acc[ms], 0, 0, 0);
+                if (st + TK_PF < 36) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
             // ---- epilogue: residual, BatchNorm-backward reductions, bf16, transposed store -------------------------------
             const __amdgpu_buffer_rsrc_t ry = bf_rsrc(a.y, xbytes);

@@ -8,7 +8,7 @@ dev = torch.device('cuda', 0)
 print(bench.kernel_rooflines(dev, 'bf16', iters=3, only=(os.environ.get('ROLE', 'fwd'),))[0]['launch_ms'])
 torch.cuda.synchronize()
 L = C.CDLL(os.environ['SISR_LIB'])
-slots = 64
+slots = 128
 buf = np.zeros(512 * slots, dtype=np.uint64)
 assert L.sisr_ttrace_read(buf.ctypes.data_as(C.c_void_p), C.c_int(buf.size)) == 0
 t = buf.reshape(512, slots).astype(np.int64) * 10e-3
@@ -22,6 +22,12 @@ for it in range(8):
     if not ok.any():
         break
     d = lambda i, j: (t[ok, j] - t[ok, i]).mean()
-    print('tile %d (n=%d): consumer MFMA %.2f  epilogue %.2f  wait at barrier %.2f   (wave 0 stamps; producers run beside)' % (
+    print('tile %d (n=%d): consumer MFMA %.2f  epilogue %.2f  wait at barrier %.2f' % (
         it, ok.sum(), d(b, b + 2), d(b + 2, b + 4), d(b + 4, b + 5)))
+    pb = 64 + b
+    okp = ok & (t[:, pb + 5] > 0) & (t[:, pb + 1] > 0)
+    if okp.any():
+        dp = lambda i, j: (t[okp, j] - t[okp, i]).mean()
+        print('          producer (wave 4): issue %.2f  wait + commit %.2f  wait at barrier %.2f' % (
+            dp(pb, pb + 1), dp(pb + 1, pb + 4), dp(pb + 4, pb + 5)))
 print('stats tail +%.2f' % (t[:, 63] - t[:, 3]).mean())
