@@ -22,6 +22,7 @@
 #include "sisr_dev.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "sisr_bf16_stage.h"
@@ -77,12 +78,63 @@ struct TrunkArgs {
     int pro;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// two floats -> one dword of two bf16 (round to nearest even): a single v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// leaky ReLU.  EASY (0 <= slope <= 1, every slope this model family uses): max(v, slope v), one multiply and one
+// v_max (as an instruction: fmaxf() adds a canonicalising v_max per operand); otherwise compare and select.
+template <bool EASY>
+__device__ __forceinline__ float lrelu_t(float v, float slope) {
+    if (EASY) {
+        float r;
+        const float sv = slope * v;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(sv));
+        return r;
+    }
+    return v > 0.f ? v : slope * v;
+}
+
+// The producers are bound by VALU issue (they share a SIMD's issue port with the consumer's MFMAs), so everything about
+// a staging item that does not depend on the tile is computed once per thread: item k of producer thread ptid is halo
+// pixel (ptid + 256 k) / 8, channel octet ptid % 8.
+//   rel[k]   byte offset of the item from the tile's first pixel in the NHWC tensor (negative in the top / left halo)
+//   ldso[k]  byte offset inside the LDS halo image
+//   flags    5 bits per item: halo row 0, halo row 9, halo column 0, halo column 17, beyond the 180 halo pixels
+// A tile turns its own edge pattern (5 bits: image above / below / left / right missing, 1) into a mask replicated over
+// the items; flags & mask is non-zero exactly for the items outside the image.
+struct HaloMap {
+    int rel[TK_ITEMS], ldso[TK_ITEMS];
+    unsigned flags;
+};
+__device__ __forceinline__ void halo_map_init(HaloMap& m, int ptid, int W) {
+    const int oct = ptid & 7;
+    m.flags = 0;
+#pragma unroll
+    for (int k = 0; k < TK_ITEMS; ++k) {
+        const int px = (ptid + k * 256) >> 3;
+        const int py = px / TK_IW, pxx = px - py * TK_IW;
+        m.rel[k] = ((py - 1) * W + (pxx - 1)) * 128 + oct * 16;
+        m.ldso[k] = px * TK_PSB + oct * 16;
+        const unsigned f = (py == 0 ? 1u : 0u) | (py == TK_IH - 1 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == TK_IW - 1 ? 8u : 0u) |
+                           (px >= TK_NPIX ? 16u : 0u);
+        m.flags |= f << (5 * k);
+    }
+}
+__device__ __forceinline__ unsigned tile_edge_mask(int ty, int tx, int tiles_y, int tiles_x) {
+    const unsigned e = (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == tiles_x - 1 ? 8u : 0u) | 16u;
+    return e * 0x02108421u;                                  // replicated at bits 0, 5, .., 25
+}
+
 // prologue of 8 consecutive channels of one pixel: a (and b) hold 8 bf16; returns 8 bf16 packed
-template <int PRO>
+template <int PRO, bool EASY>
 __device__ __forceinline__ u32x4 trunk_apply8(u32x4 a, u32x4 b, const f32x8& ka, const f32x8& kb, const f32x8& kd,
                                               const f32x8& ks, const f32x8& kt, float slope, bool ok) {
     if (PRO == SISR_PRO_NONE) return a;                       // zeros outside the image already (hardware OOB)
-    float v[8];
+    u32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float a0 = __uint_as_float(a[j] << 16), a1 = __uint_as_float(a[j] & 0xFFFF0000u);
@@ -91,9 +143,9 @@ __device__ __forceinline__ u32x4 trunk_apply8(u32x4 a, u32x4 b, const f32x8& ka,
             b0 = __uint_as_float(b[j] << 16); b1 = __uint_as_float(b[j] & 0xFFFF0000u);
         }
         float r0, r1;
-        if (PRO == SISR_PRO_ACT) { r0 = lrelu(a0, slope); r1 = lrelu(a1, slope); }
+        if (PRO == SISR_PRO_ACT) { r0 = lrelu_t<EASY>(a0, slope); r1 = lrelu_t<EASY>(a1, slope); }
         else if (PRO == SISR_PRO_AFFINE_ACT) {
-            r0 = lrelu(ka[2 * j] * a0 + kd[2 * j], slope); r1 = lrelu(ka[2 * j + 1] * a1 + kd[2 * j + 1], slope);
+            r0 = lrelu_t<EASY>(ka[2 * j] * a0 + kd[2 * j], slope); r1 = lrelu_t<EASY>(ka[2 * j + 1] * a1 + kd[2 * j + 1], slope);
         } else if (PRO == SISR_PRO_BNBWD) {
             r0 = ka[2 * j] * a0 + kb[2 * j] * b0 + kd[2 * j];
             r1 = ka[2 * j + 1] * a1 + kb[2 * j + 1] * b1 + kd[2 * j + 1];
@@ -103,14 +155,9 @@ __device__ __forceinline__ u32x4 trunk_apply8(u32x4 a, u32x4 b, const f32x8& ka,
             r0 = ka[2 * j] * g0 + kb[2 * j] * b0 + kd[2 * j];
             r1 = ka[2 * j + 1] * g1 + kb[2 * j + 1] * b1 + kd[2 * j + 1];
         }
-        v[2 * j] = r0; v[2 * j + 1] = r1;
-    }
-    u32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned lo = f32_to_bf16_bits(v[2 * j]), hi = f32_to_bf16_bits(v[2 * j + 1]);
         // prologues with f(0) != 0: the halo must be zero AFTER the transform
-        o[j] = (PRO == SISR_PRO_ACT || ok) ? (lo | (hi << 16)) : 0u;
+        const unsigned pk = pack_bf16x2(r0, r1);
+        o[j] = (PRO == SISR_PRO_ACT || ok) ? pk : 0u;
     }
     return o;
 }
@@ -156,6 +203,8 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     float slope = 1.f;
     u32x4 sreg[TK_ITEMS];
     unsigned sok = 0;
+    HaloMap hm;
+    bool easy_slope = true;
 
     TT(0);
     // (role state is set up INSIDE the role branches below: set up ahead of the split, every register of both roles
@@ -177,6 +226,8 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     };
     auto init_producer = [&]() {
         slope = a.slope_p ? a.slope_p[0] : a.slope;
+        easy_slope = slope >= 0.f && slope <= 1.f;
+        halo_map_init(hm, ptid, a.W);
         if (PRO == SISR_PRO_AFFINE_ACT) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { ka[j] = a.pa[oct * 8 + j]; kd[j] = a.pd[oct * 8 + j]; }
@@ -186,29 +237,32 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     // LDS, so the producers never sit out a full memory latency (they are the critical path otherwise)
     u32x4 sreg2[TK_ITEMS];
     unsigned sok2 = 0;
-    auto issue = [&](int T, u32x4 (&sr)[TK_ITEMS], unsigned& okm) {
+    const int tiles_y = a.per_img / a.tiles_x;
+    auto issue = [&](int T, u32x4 (&sr)[TK_ITEMS], unsigned& bad) {
         const __amdgpu_buffer_rsrc_t rx = bf_rsrc(a.x1, xbytes);
         int n, ty, tx;
         tile_coords(T, n, ty, tx);
-        okm = 0;
+        const unsigned origin = (unsigned)(((n * a.H + ty * TK_TH) * a.W + tx * TK_TW) * 128);
+        bad = hm.flags & tile_edge_mask(ty, tx, tiles_y, a.tiles_x);
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
-            const int idx = ptid + k * 256, px = idx >> 3;
-            const int py = px / TK_IW, pxx = px - py * TK_IW;
-            const int iy = ty * TK_TH - 1 + py, ix = tx * TK_TW - 1 + pxx;
-            const bool ok = px < TK_NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned voff = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * 128 + oct * 16) : 0x80000000u;
-            sr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0);
-            okm |= ok ? (1u << k) : 0u;
+            const bool ok = ((bad >> (5 * k)) & 31u) == 0u;
+            sr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? origin + (unsigned)hm.rel[k] : 0x80000000u, 0, 0);
         }
     };
-    auto commit = [&](unsigned char* buf, const u32x4 (&sr)[TK_ITEMS], unsigned okm) {
+    auto commit_t = [&](auto easy, unsigned char* buf, const u32x4 (&sr)[TK_ITEMS], unsigned bad) {
+        constexpr bool EASY = decltype(easy)::value;
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
-            const int idx = ptid + k * 256, px = idx >> 3;
-            const u32x4 v = trunk_apply8<PRO>(sr[k], sr[k], ka, ka, kd, ka, ka, slope, (okm >> k) & 1u);
-            if (px < TK_NPIX) *reinterpret_cast<u32x4*>(buf + px * TK_PSB + oct * 16) = v;
+            const bool ok = ((bad >> (5 * k)) & 31u) == 0u;
+            const u32x4 v = trunk_apply8<PRO, EASY>(sr[k], sr[k], ka, ka, kd, ka, ka, slope, ok);
+            // (only the last item of a thread can lie beyond the 180 halo pixels)
+            if (k < TK_ITEMS - 1 || !((hm.flags >> (5 * k + 4)) & 1u)) *reinterpret_cast<u32x4*>(buf + hm.ldso[k]) = v;
         }
+    };
+    auto commit = [&](unsigned char* buf, const u32x4 (&sr)[TK_ITEMS], unsigned bad) {
+        if (easy_slope) commit_t(std::true_type{}, buf, sr, bad);
+        else commit_t(std::false_type{}, buf, sr, bad);
     };
     __bf16* my_out = out_img + (wave & 3) * (32 * TK_YS);
     const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
@@ -258,7 +312,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
 #pragma unroll
             for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[ms][i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[ms][i] = bv;          // the bias: every register of a lane is its channel
             const unsigned char* ib = lds + cur * (TK_NPIX * TK_PSB);
             // software pipeline: the A fragments of step s + TK_PF are requested before the two MFMAs of step s
             // (step = tap t, K slice j; left to itself the compiler keeps one step of reads in flight, ~64 cycles of cover)
@@ -286,10 +340,6 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
             const __amdgpu_buffer_rsrc_t ry = bf_rsrc(a.y, xbytes);
             int n, ty, tx;
             tile_coords(T, n, ty, tx);
-#pragma unroll
-            for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[ms][i] += bv;
             if (a.stat_part != nullptr) {
                 if (st_n == 0) {                                    // shift = mean of the first tile's values of this lane
                     float s = 0.f;
@@ -434,25 +484,20 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
     // two staging register sets: the loads of tile T + 2 are in flight while tile T + 1 is transformed and written to LDS
     u32x4 sa2[TK_ITEMS], sb2[TK_ITEMS];
     unsigned sok2 = 0;
-    auto issue = [&](int T, u32x4 (&ra)[TK_ITEMS], u32x4 (&rb)[TK_ITEMS], unsigned& okm) {
+    HaloMap hm;
+    const int tiles_y = a.per_img / a.tiles_x;
+    auto issue = [&](int T, u32x4 (&ra)[TK_ITEMS], u32x4 (&rb)[TK_ITEMS], unsigned& bad) {
         const __amdgpu_buffer_rsrc_t r1 = bf_rsrc(a.x1, xbytes), r2 = bf_rsrc(a.x2, xbytes);
         int n, ty, tx;
         tile_coords(T, n, ty, tx);
-        okm = 0;
-        // (opaque copies: the per-item index arithmetic is recomputed per tile instead of being hoisted out of the tile
-        // loop into registers)
-        int pt_ = ptid;
-        asm volatile("" : "+v"(pt_));
+        const unsigned origin = (unsigned)(((n * a.H + ty * TK_TH) * a.W + tx * TK_TW) * 128);
+        bad = hm.flags & tile_edge_mask(ty, tx, tiles_y, a.tiles_x);
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
-            const int idx = pt_ + k * 256, px = idx >> 3;
-            const int py = px / TK_IW, pxx = px - py * TK_IW;
-            const int iy = ty * TK_TH - 1 + py, ix = tx * TK_TW - 1 + pxx;
-            const bool ok = px < TK_NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned voff = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * 128 + oct * 16) : 0x80000000u;
+            const bool ok = ((bad >> (5 * k)) & 31u) == 0u;
+            const unsigned voff = ok ? origin + (unsigned)hm.rel[k] : 0x80000000u;
             ra[k] = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0);
             rb[k] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0);
-            okm |= ok ? (1u << k) : 0u;
         }
     };
     // the tile's own 128 pixels x 8 octets of the residual and of the BatchNorm input, LDS-direct into image buffer b:
@@ -484,15 +529,14 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
     // its own register budget, and a producer that reads LDS would wait for its LDS-direct loads first)
     const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x8 ka = zero8, kb = zero8, kd = zero8, ks = zero8, kt = zero8;
-    auto commit = [&](int b, const u32x4 (&ra)[TK_ITEMS], const u32x4 (&rb)[TK_ITEMS], unsigned okm) {
+    auto commit = [&](int b, const u32x4 (&ra)[TK_ITEMS], const u32x4 (&rb)[TK_ITEMS], unsigned bad) {
         unsigned char* buf = lds + b * (TK_NPIX * TK_PSB);
-        int pt_ = ptid;
-        asm volatile("" : "+v"(pt_));
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
-            const int idx = pt_ + k * 256, px = idx >> 3;
-            const u32x4 v = trunk_apply8<PRO>(ra[k], rb[k], ka, kb, kd, ks, kt, slope, (okm >> k) & 1u);
-            if (px < TK_NPIX) *reinterpret_cast<u32x4*>(buf + px * TK_PSB + (pt_ & 7) * 16) = v;
+            const bool ok = ((bad >> (5 * k)) & 31u) == 0u;
+            const u32x4 v = trunk_apply8<PRO, false>(ra[k], rb[k], ka, kb, kd, ks, kt, slope, ok);
+            // (only the last item of a thread can lie beyond the 180 halo pixels)
+            if (k < TK_ITEMS - 1 || !((hm.flags >> (5 * k + 4)) & 1u)) *reinterpret_cast<u32x4*>(buf + hm.ldso[k]) = v;
         }
     };
     __bf16* my_out = out_img + (wave & 3) * (32 * TK_YS);
@@ -501,6 +545,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
     // role-specific tile loops with matching barrier counts (see the forward kernel)
     if (!consumer) {
         slope = a.slope_p ? a.slope_p[0] : a.slope;
+        halo_map_init(hm, ptid, a.W);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             ka[j] = a.pa[oct * 8 + j]; kb[j] = a.pb[oct * 8 + j]; kd[j] = a.pd[oct * 8 + j];
