@@ -228,7 +228,14 @@ def kernel_rooflines(device, precision, iters=40, only=None):
     fam = 'bf16' if precision == 'bf16' else 'f32'
     names = {'fwd': 'conv_mfma_%s_kernel (trunk 3x3 64->64, forward role)' % fam,
              'dgrad': 'conv_mfma_%s_kernel (trunk 3x3 64->64, data-gradient role)' % fam,
-             'wgrad': 'wgrad_mfma_%s_kernel + slab reduction (trunk 3x3 64->64)' % fam}
+             'wgrad': 'wgrad_mfma_%s_kernel + slab_reduce_kernel (trunk 3x3 64->64)' % fam}
+    if precision == 'bf16' and elt == 2 and os.environ.get('SISR_TRUNK', '1') != '0':
+        # bf16 tensors: the persistent trunk kernels (conv_trunk.hip, wgrad_trunk.hip) take this geometry
+        names = {'fwd': 'conv_trunk_fwd_kernel (trunk 3x3 64->64, forward role)',
+                 'dgrad': 'conv_trunk_bwd_kernel (trunk 3x3 64->64, data-gradient role)',
+                 'wgrad': 'wgrad_trunk_kernel + slab_reduce_kernel (trunk 3x3 64->64)'}
+        if os.environ.get('SISR_TRUNK_WGRAD', '1') == '0':
+            names['wgrad'] = 'wgrad_mfma_bf16_kernel + slab_reduce_kernel (trunk 3x3 64->64)'
     out_rec = {}
     if only is not None:                         # developer tools (tools/trace_conv.py, tools/prof_conv.py): one role
         roles = {r: v for r, v in roles.items() if r in only}
