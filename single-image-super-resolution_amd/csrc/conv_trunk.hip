@@ -32,7 +32,13 @@
 #define TK_IH (TK_TH + 2)
 #define TK_IW (TK_TW + 2)
 #define TK_NPIX (TK_IH * TK_IW)          // 180 halo pixels
-#define TK_PSB 144                        // LDS bytes per halo pixel: 64 bf16 + 16 bytes of padding
+// LDS halo image: pixel (py, pxx) at py * TK_RP + pxx * TK_PSB.  160 bytes per pixel and 16 bytes of padding per row
+// make the consumers' ds_read_b128 of an A fragment (lanes 0-15: 16 pixels of one halo row, lanes 16-31: the row below,
+// served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}) conflict-free; a plain 144-byte pixel stride
+// costs two extra LDS cycles per read (44 % of all LDS cycles, SQ_LDS_BANK_CONFLICT).
+#define TK_PSB 160
+#define TK_RP (TK_IW * TK_PSB + 16)
+#define TK_HALO_BYTES (TK_IH * TK_RP)     // 28960
 #define TK_ITEMS ((TK_NPIX * 8 + 255) / 256)   // 16-byte staging items per producer thread (6)
 #define TK_YS 68                          // output image: [32 couts][64 pixels + 4] bf16 per wave
 
@@ -118,7 +124,7 @@ __device__ __forceinline__ void halo_map_init(HaloMap& m, int ptid, int W) {
         const int px = (ptid + k * 256) >> 3;
         const int py = px / TK_IW, pxx = px - py * TK_IW;
         m.rel[k] = ((py - 1) * W + (pxx - 1)) * 128 + oct * 16;
-        m.ldso[k] = px * TK_PSB + oct * 16;
+        m.ldso[k] = py * TK_RP + pxx * TK_PSB + oct * 16;
         const unsigned f = (py == 0 ? 1u : 0u) | (py == TK_IH - 1 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == TK_IW - 1 ? 8u : 0u) |
                            (px >= TK_NPIX ? 16u : 0u);
         m.flags |= f << (5 * k);
@@ -174,8 +180,8 @@ __device__ __forceinline__ u32x4 trunk_apply8(u32x4 a, u32x4 b, const f32x8& ka,
 template <int PRO>
 __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const TrunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    __bf16* out_img = reinterpret_cast<__bf16*>(lds + 2 * TK_NPIX * TK_PSB);            // [4 waves][32][TK_YS]
-    float* red = reinterpret_cast<float*>(lds + 2 * TK_NPIX * TK_PSB + 4 * 32 * TK_YS * 2);   // [4 waves][32][3]
+    __bf16* out_img = reinterpret_cast<__bf16*>(lds + 2 * TK_HALO_BYTES);            // [4 waves][32][TK_YS]
+    float* red = reinterpret_cast<float*>(lds + 2 * TK_HALO_BYTES + 4 * 32 * TK_YS * 2);   // [4 waves][32][3]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // provably wave-uniform
@@ -221,7 +227,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
             }
         // A operand of sub-tile ms: lane (l31, kk) = pixel (tile row 4g + 2ms + (l31 >> 4), column l31 & 15), channels 8kk..
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms) a_base[ms] = ((4 * g + 2 * ms + (l31 >> 4)) * TK_IW + (l31 & 15)) * TK_PSB + kk * 16;
+        for (int ms = 0; ms < 2; ++ms) a_base[ms] = (4 * g + 2 * ms + (l31 >> 4)) * TK_RP + (l31 & 15) * TK_PSB + kk * 16;
         bv = a.bias != nullptr ? a.bias[32 * h + l31] : 0.f;
     };
     auto init_producer = [&]() {
@@ -289,11 +295,11 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
             if (it & 1) {
                 if (Tnn < a.total) issue(Tnn, sreg2, sok2);
                 TTP(5 + 6 * it);
-                if (Tn < a.total) commit(lds + (cur ^ 1) * (TK_NPIX * TK_PSB), sreg, sok);
+                if (Tn < a.total) commit(lds + (cur ^ 1) * (TK_HALO_BYTES), sreg, sok);
             } else {
                 if (Tnn < a.total) issue(Tnn, sreg, sok);
                 TTP(5 + 6 * it);
-                if (Tn < a.total) commit(lds + (cur ^ 1) * (TK_NPIX * TK_PSB), sreg2, sok2);
+                if (Tn < a.total) commit(lds + (cur ^ 1) * (TK_HALO_BYTES), sreg2, sok2);
             }
             TTP(8 + 6 * it);
             __syncthreads();
@@ -313,13 +319,13 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
             for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[ms][i] = bv;          // the bias: every register of a lane is its channel
-            const unsigned char* ib = lds + cur * (TK_NPIX * TK_PSB);
+            const unsigned char* ib = lds + cur * (TK_HALO_BYTES);
             // software pipeline: the A fragments of step s + TK_PF are requested before the two MFMAs of step s
             // (step = tap t, K slice j; left to itself the compiler keeps one step of reads in flight, ~64 cycles of cover)
             bf16x8 af[36][2];
             auto fetch = [&](int st) {
                 const int t = st >> 2, j = st & 3;
-                const int toff = ((t / 3) * TK_IW + (t % 3)) * TK_PSB;
+                const int toff = (t / 3) * TK_RP + (t % 3) * TK_PSB;
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms) af[st][ms] = *reinterpret_cast<const bf16x8*>(ib + a_base[ms] + toff + j * 32);
             };
@@ -435,9 +441,9 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
 template <int PRO>
 __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const TrunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    __bf16* out_img = reinterpret_cast<__bf16*>(lds + 2 * TK_NPIX * TK_PSB);            // [4 waves][32][TK_YS]
-    float* red = reinterpret_cast<float*>(lds + 2 * TK_NPIX * TK_PSB + 4 * 32 * TK_YS * 2);   // [4 waves][32][2] + [4]
-    unsigned char* img0 = lds + 2 * TK_NPIX * TK_PSB + 4 * 32 * TK_YS * 2 + TK_RED_BYTES;   // [2 buffers][res, bnb_x][TK_IMG]
+    __bf16* out_img = reinterpret_cast<__bf16*>(lds + 2 * TK_HALO_BYTES);            // [4 waves][32][TK_YS]
+    float* red = reinterpret_cast<float*>(lds + 2 * TK_HALO_BYTES + 4 * 32 * TK_YS * 2);   // [4 waves][32][2] + [4]
+    unsigned char* img0 = lds + 2 * TK_HALO_BYTES + 4 * 32 * TK_YS * 2 + TK_RED_BYTES;   // [2 buffers][res, bnb_x][TK_IMG]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -475,7 +481,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
                 bw[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
             }
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms) a_base[ms] = ((4 * g + 2 * ms + (l31 >> 4)) * TK_IW + (l31 & 15)) * TK_PSB + kk * 16;
+        for (int ms = 0; ms < 2; ++ms) a_base[ms] = (4 * g + 2 * ms + (l31 >> 4)) * TK_RP + (l31 & 15) * TK_PSB + kk * 16;
         if (has_x) {
             b_sc = a.bnb_scale[co]; b_sf = a.bnb_shift[co]; b_mu = a.bnb_mean[co]; b_is = a.bnb_invstd[co];
             b_slope = a.bnb_slope_p ? a.bnb_slope_p[0] : a.bnb_slope;
@@ -530,7 +536,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
     const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x8 ka = zero8, kb = zero8, kd = zero8, ks = zero8, kt = zero8;
     auto commit = [&](int b, const u32x4 (&ra)[TK_ITEMS], const u32x4 (&rb)[TK_ITEMS], unsigned bad) {
-        unsigned char* buf = lds + b * (TK_NPIX * TK_PSB);
+        unsigned char* buf = lds + b * (TK_HALO_BYTES);
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
             const bool ok = ((bad >> (5 * k)) & 31u) == 0u;
@@ -585,13 +591,13 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
             for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[ms][i] = 0.f;
-            const unsigned char* ib = lds + cur * (TK_NPIX * TK_PSB);
+            const unsigned char* ib = lds + cur * (TK_HALO_BYTES);
             // software pipeline: the A fragments of step s + TK_PF are requested before the two MFMAs of step s
             // (step = tap t, K slice j; left to itself the compiler keeps one step of reads in flight, ~64 cycles of cover)
             bf16x8 af[36][2];
             auto fetch = [&](int st) {
                 const int t = st >> 2, j = st & 3;
-                const int toff = ((t / 3) * TK_IW + (t % 3)) * TK_PSB;
+                const int toff = (t / 3) * TK_RP + (t % 3) * TK_PSB;
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms) af[st][ms] = *reinterpret_cast<const bf16x8*>(ib + a_base[ms] + toff + j * 32);
             };
@@ -733,7 +739,7 @@ extern "C" int sisr_conv2d_bf16_parts(const SisrConvDesc* d) {
 
 template <int PRO>
 static int launch_trunk_fwd(const TrunkArgs& a, int grid, hipStream_t st) {
-    constexpr int lds_bytes = 2 * TK_NPIX * TK_PSB + 4 * 32 * TK_YS * 2 + 4 * 32 * 3 * 4;
+    constexpr int lds_bytes = 2 * TK_HALO_BYTES + 4 * 32 * TK_YS * 2 + 4 * 32 * 3 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_trunk_fwd_kernel<PRO>),
@@ -748,7 +754,7 @@ static int launch_trunk_fwd(const TrunkArgs& a, int grid, hipStream_t st) {
 
 template <int PRO>
 static int launch_trunk_bwd(const TrunkArgs& a, int grid, bool images, hipStream_t st) {
-    const int lds_bytes = 2 * TK_NPIX * TK_PSB + 4 * 32 * TK_YS * 2 + TK_RED_BYTES + (images ? 4 * TK_IMG : 0);
+    const int lds_bytes = 2 * TK_HALO_BYTES + 4 * 32 * TK_YS * 2 + TK_RED_BYTES + (images ? 4 * TK_IMG : 0);
     static int lds_max = 0;
     if (lds_bytes > lds_max) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_trunk_bwd_kernel<PRO>),
