@@ -84,26 +84,6 @@ struct TrunkArgs {
     int pro;
 };
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-// two floats -> one dword of two bf16 (round to nearest even): a single v_cvt_pk_bf16_f32
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-// leaky ReLU.  EASY (0 <= slope <= 1, every slope this model family uses): max(v, slope v), one multiply and one
-// v_max (as an instruction: fmaxf() adds a canonicalising v_max per operand); otherwise compare and select.
-template <bool EASY>
-__device__ __forceinline__ float lrelu_t(float v, float slope) {
-    if (EASY) {
-        float r;
-        const float sv = slope * v;
-        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(sv));
-        return r;
-    }
-    return v > 0.f ? v : slope * v;
-}
-
 // The producers are bound by VALU issue (they share a SIMD's issue port with the consumer's MFMAs), so everything about
 // a staging item that does not depend on the tile is computed once per thread: item k of producer thread ptid is halo
 // pixel (ptid + 256 k) / 8, channel octet ptid % 8.
@@ -249,7 +229,10 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
         int n, ty, tx;
         tile_coords(T, n, ty, tx);
         const unsigned origin = (unsigned)(((n * a.H + ty * TK_TH) * a.W + tx * TK_TW) * 128);
-        bad = hm.flags & tile_edge_mask(ty, tx, tiles_y, a.tiles_x);
+        // (always executed, so that the tile loop stays free of control flow around loads: past the last tile every
+        // item is "outside", which costs an instruction and no memory traffic.  With a branch around the loads the
+        // compiler's wait-count bookkeeping gives up at the merge and drains every load before the next commit.)
+        bad = T < a.total ? hm.flags & tile_edge_mask(ty, tx, tiles_y, a.tiles_x) : 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
             const bool ok = ((bad >> (5 * k)) & 31u) == 0u;
@@ -280,30 +263,32 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
         // ---- producers: tile T + 1 into the other buffer while the consumers work on tile T ------------------------------
         init_producer();
         int T = blockIdx.x;
-        if (T < a.total) {
-            issue(T, sreg, sok);
-            if (T + (int)gridDim.x < a.total) issue(T + gridDim.x, sreg2, sok2);
-            commit(lds, sreg, sok);
-        }
+        issue(T, sreg, sok);
+        issue(T + gridDim.x, sreg2, sok2);
+        if (T < a.total) commit(lds, sreg, sok);
         TTP(2);
         __syncthreads();
-        int cur = 0, it = 0;
-        for (; T < a.total; T += gridDim.x, cur ^= 1, ++it) {
-            const int Tn = T + gridDim.x, Tnn = Tn + gridDim.x;
+        // unrolled by two: each staging set has a fixed name in each half (sreg2 holds tile T + grid in the first)
+        int cur = 0;
+        [[maybe_unused]] int it = 0;
+        while (T < a.total) {
             TTP(4 + 6 * it);
-            // tile Tn is in the set filled one iteration ago (sreg2 on even iterations); tile Tnn goes into the other one
-            if (it & 1) {
-                if (Tnn < a.total) issue(Tnn, sreg2, sok2);
-                TTP(5 + 6 * it);
-                if (Tn < a.total) commit(lds + (cur ^ 1) * (TK_HALO_BYTES), sreg, sok);
-            } else {
-                if (Tnn < a.total) issue(Tnn, sreg, sok);
-                TTP(5 + 6 * it);
-                if (Tn < a.total) commit(lds + (cur ^ 1) * (TK_HALO_BYTES), sreg2, sok2);
-            }
+            issue(T + 2 * gridDim.x, sreg, sok);
+            TTP(5 + 6 * it);
+            if (T + (int)gridDim.x < a.total) commit(lds + (cur ^ 1) * TK_HALO_BYTES, sreg2, sok2);
             TTP(8 + 6 * it);
             __syncthreads();
             TTP(9 + 6 * it);
+            T += gridDim.x; cur ^= 1; ++it;
+            if (T >= a.total) break;
+            TTP(4 + 6 * it);
+            issue(T + 2 * gridDim.x, sreg2, sok2);
+            TTP(5 + 6 * it);
+            if (T + (int)gridDim.x < a.total) commit(lds + (cur ^ 1) * TK_HALO_BYTES, sreg, sok);
+            TTP(8 + 6 * it);
+            __syncthreads();
+            TTP(9 + 6 * it);
+            T += gridDim.x; cur ^= 1; ++it;
         }
     } else {
         init_consumer();
@@ -497,7 +482,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
         int n, ty, tx;
         tile_coords(T, n, ty, tx);
         const unsigned origin = (unsigned)(((n * a.H + ty * TK_TH) * a.W + tx * TK_TW) * 128);
-        bad = hm.flags & tile_edge_mask(ty, tx, tiles_y, a.tiles_x);
+        bad = T < a.total ? hm.flags & tile_edge_mask(ty, tx, tiles_y, a.tiles_x) : 0xFFFFFFFFu;   // (always executed: see the forward kernel)
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
             const bool ok = ((bad >> (5 * k)) & 31u) == 0u;
@@ -558,27 +543,26 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
             if (PRO == SISR_PRO_BNACT_BWD) { ks[j] = a.ps[oct * 8 + j]; kt[j] = a.pt[oct * 8 + j]; }
         }
         int T = blockIdx.x;
-        if (T < a.total) {
-            issue_images(T, 0);
-            issue(T, sa, sb, sok);
-            if (T + (int)gridDim.x < a.total) issue(T + gridDim.x, sa2, sb2, sok2);
-            commit(0, sa, sb, sok);
-        }
+        if (T < a.total) issue_images(T, 0);
+        issue(T, sa, sb, sok);
+        issue(T + gridDim.x, sa2, sb2, sok2);
+        if (T < a.total) commit(0, sa, sb, sok);
         __syncthreads();
-        int cur = 0, it = 0;
-        for (; T < a.total; T += gridDim.x, cur ^= 1, ++it) {
-            const int Tn = T + gridDim.x, Tnn = Tn + gridDim.x;
-            // register loads of tile Tnn and LDS-direct loads of tile Tn go out back to back, then tile Tn is committed from
-            // the register set filled one iteration ago (sa2 / sb2 on even iterations) while they fly.  The barrier's fence
-            // drains them all (it must, for the LDS-direct ones), which costs little: they were issued together.
-            if (it & 1) {
-                if (Tnn < a.total) issue(Tnn, sa2, sb2, sok2);
-                if (Tn < a.total) { issue_images(Tn, cur ^ 1); commit(cur ^ 1, sa, sb, sok); }
-            } else {
-                if (Tnn < a.total) issue(Tnn, sa, sb, sok);
-                if (Tn < a.total) { issue_images(Tn, cur ^ 1); commit(cur ^ 1, sa2, sb2, sok2); }
-            }
+        // Per half: register loads of tile T + 2 grid and LDS-direct loads of tile T + grid go out back to back, then tile
+        // T + grid is committed from the set filled one half ago while they fly.  The barrier's fence drains them all (it
+        // must, for the LDS-direct ones), which costs little: they were issued together.  Unrolled by two: each staging
+        // set has a fixed name in each half.
+        int cur = 0;
+        while (T < a.total) {
+            issue(T + 2 * gridDim.x, sa, sb, sok);
+            if (T + (int)gridDim.x < a.total) { issue_images(T + gridDim.x, cur ^ 1); commit(cur ^ 1, sa2, sb2, sok2); }
             __syncthreads();
+            T += gridDim.x; cur ^= 1;
+            if (T >= a.total) break;
+            issue(T + 2 * gridDim.x, sa2, sb2, sok2);
+            if (T + (int)gridDim.x < a.total) { issue_images(T + gridDim.x, cur ^ 1); commit(cur ^ 1, sa, sb, sok); }
+            __syncthreads();
+            T += gridDim.x; cur ^= 1;
         }
     } else {
         init_consumer();

@@ -29,6 +29,26 @@ __device__ __forceinline__ f32x4 bf16x4_bits_to_f32(u32x2 w) {
     return v;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// two floats -> one dword of two bf16 (round to nearest even): a single v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// leaky ReLU.  EASY (0 <= slope <= 1, every slope this model family uses): max(v, slope v), one multiply and one
+// v_max (as an instruction: fmaxf() adds a canonicalising v_max per operand); otherwise compare and select.
+template <bool EASY>
+__device__ __forceinline__ float lrelu_t(float v, float slope) {
+    if (EASY) {
+        float r;
+        const float sv = slope * v;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(sv));
+        return r;
+    }
+    return v > 0.f ? v : slope * v;
+}
+
 // float4 staging with the prologue fixed at compile time, bf16 LDS image.
 // Addressing is the cheap part by construction: a thread's items walk the tile in steps of `ppi` pixels, so
 // its (row, column) and the two offset terms advance by adds; loads are raw buffer loads with a 32-bit byte

@@ -14,7 +14,8 @@
 //     accumulators of its four consumer waves (9 taps x 16 registers each) across all of its tiles: one slab per
 //     workgroup (<= 256), written once;
 //   * four producer waves stage the next tile (both prologues, bias sums on the fly) into the other LDS buffer while
-//     the consumers multiply the current one: one barrier per tile;
+//     the consumers multiply the current one: one barrier per tile (the consumers stage the x operand themselves, after
+//     their MFMAs: see the kernel);
 //   * the contraction runs over pixels, so both MFMA operands are fetched with transposing LDS reads from pixel-major
 //     images (pixel stride 192 bytes: the 4 pixel rows of a read sit 48 banks apart).  An x fragment (halo row R,
 //     column shift kx) serves the three taps (ky, kx) of tile rows R - ky: 76 reads feed the 72 MFMAs of a tile.
@@ -23,6 +24,7 @@
 #include "sisr_bf16_stage.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #define WT_TH 8
@@ -35,6 +37,19 @@
 #define WT_DBYTES (128 * WT_PS)             // 24576
 #define WT_XITEMS ((WT_NPIX * 8 + 255) / 256)   // 6
 #define WT_THREADS 512
+
+// phase timeline, developer build only (make trace; tools/trace_trunk.py with ROLE=wgrad)
+#ifdef SISR_CONV_TRACE
+__device__ unsigned long long sisr_wttrace_buf[512 * 128];
+#define WTT(k) do { if (threadIdx.x == 0 && blockIdx.x < 512 && (k) < 64) sisr_wttrace_buf[blockIdx.x * 128 + (k)] = wall_clock64(); } while (0)
+#define WTTP(k) do { if (threadIdx.x == 256 && blockIdx.x < 512 && (k) < 64) sisr_wttrace_buf[blockIdx.x * 128 + 64 + (k)] = wall_clock64(); } while (0)
+extern "C" int sisr_wttrace_read(void* dst, int n_u64) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sisr_wttrace_buf), (size_t)n_u64 * 8, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define WTT(k)
+#define WTTP(k)
+#endif
 
 struct WTrunkArgs {
     const void *x1, *g1, *g2;
@@ -55,11 +70,33 @@ __device__ __forceinline__ bf16x8 wt_frag(const unsigned char* p) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// x prologue of one thread's staged halo items: lrelu(a x + d) (a = 1, d = 0, slope = 1 degenerate to ACT / NONE), zero
+// outside the image; dst0 = the thread's first LDS slot, item k sits 32 pixels further
+template <bool EASY>
+__device__ __forceinline__ void wt_commit_x(const u32x4 (&sx)[WT_XITEMS], unsigned bad, unsigned xflags, const float* kst, int oct,
+                                            float xslope, unsigned char* dst0) {
+    const f32x8 ka = *reinterpret_cast<const f32x8*>(kst + oct * 8), kd = *reinterpret_cast<const f32x8*>(kst + 64 + oct * 8);
+#pragma unroll
+    for (int k = 0; k < WT_XITEMS; ++k) {
+        const bool ok = ((bad >> (5 * k)) & 31u) == 0u;
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v0 = __uint_as_float(sx[k][j] << 16), v1 = __uint_as_float(sx[k][j] & 0xFFFF0000u);
+            const float r0 = lrelu_t<EASY>(ka[2 * j] * v0 + kd[2 * j], xslope), r1 = lrelu_t<EASY>(ka[2 * j + 1] * v1 + kd[2 * j + 1], xslope);
+            const unsigned pk = pack_bf16x2(r0, r1);
+            o[j] = ok ? pk : 0u;
+        }
+        // (only the last item of a thread can lie beyond the 180 halo pixels)
+        if (k < WT_XITEMS - 1 || !((xflags >> (5 * k + 4)) & 1u)) *reinterpret_cast<u32x4*>(dst0 + k * 32 * WT_PS) = o;
+    }
+}
+
 template <int GPRO>
 __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    // [2 buffers][x halo image | dy image], then the prologue constants
-    float* kst = reinterpret_cast<float*>(lds + 2 * (WT_XBYTES + WT_DBYTES));      // xa, xd, qa, qb, qd, qs, qt: [7][64]
+    // [2 buffers][x halo image | dy image], then the x prologue constants
+    float* kst = reinterpret_cast<float*>(lds + 2 * (WT_XBYTES + WT_DBYTES));      // xa, xd: [2][64]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,164 +110,170 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
         ty = fdiv(rem, a.m_tiles_x);
         tx = rem - ty * a.tiles_x;
     };
+    auto tile_origin = [&](int T, int& ty, int& tx) {
+        int n;
+        tile_coords(T, n, ty, tx);
+        return (unsigned)(((n * a.H + ty * WT_TH) * a.W + tx * WT_TW) * 128);
+    };
 
     if (tid < 64) {
         const bool aff = a.xpro == SISR_PRO_AFFINE_ACT;
         kst[tid] = aff ? a.pa[tid] : 1.f;
         kst[64 + tid] = aff ? a.pd[tid] : 0.f;
-        kst[128 + tid] = a.qa[tid]; kst[192 + tid] = a.qb[tid]; kst[256 + tid] = a.qd[tid];
-        kst[320 + tid] = GPRO == SISR_PRO_BNACT_BWD ? a.qs[tid] : 0.f;
-        kst[384 + tid] = GPRO == SISR_PRO_BNACT_BWD ? a.qt[tid] : 0.f;
     }
     __syncthreads();
 
-    // ---- consumer state: the whole gradient of (32 output channels) x (9 taps x 32 input channels) --------------------
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    // transposing-read lane roles: 16-lane group grp -> (channel half grp & 1, pixel half grp >> 1 of the 16-pixel K
-    // step); inside the group lane 4q + p addresses (pixel row q, channels 4p .. 4p + 3)
-    const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-    const int rd_pix = (8 * (grp >> 1) + tq) * WT_PS + (16 * (grp & 1) + 4 * tp) * 2;
-    // ---- producer state ------------------------------------------------------------------------------------------------
-    const int ptid = tid & 255;
-    float xslope = 1.f, gslope = 1.f;
-    f32x8 bsum = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // bias gradient: this thread's 8 channels, its pixels
-    u32x4 sx[WT_XITEMS], s1[4], s2[4];
-    unsigned sok = 0;
-    if (!consumer) {
-        if (a.xpro != SISR_PRO_NONE) xslope = a.xslope_p ? a.xslope_p[0] : a.xslope;
-        gslope = a.gslope_p ? a.gslope_p[0] : a.gslope;
-    }
+    // Staging items: thread pt (0 .. 255 of its role), item k = pixel pt / 8 + 32 k of the halo (x, 6 items, the last one
+    // partly beyond the 180 halo pixels) or of the tile (gradient, 4 items), channel octet pt % 8.  Both roles are bound by
+    // VALU issue while they stage, so everything about an item that does not depend on the tile is computed once.
+    const int pt = tid & 255, oct = tid & 7, m0 = pt >> 3;
+    float* sl = a.slab + (int64_t)blockIdx.x * a.slab_stride;
 
-    // Producer schedule of one tile: every load of the tile in flight (56 registers), then the commits in issue order.
-    int pn = 0, pty = 0, ptx = 0;
-    auto issue_x = [&](int T) {
-        const __amdgpu_buffer_rsrc_t rx = bf_rsrc(a.x1, xbytes);
-        tile_coords(T, pn, pty, ptx);
-        sok = 0;
-        int pt_ = ptid;                              // (opaque: per-item index arithmetic stays inside the tile loop)
-        asm volatile("" : "+v"(pt_));
-        const int oct = pt_ & 7;
+    // Two role-specific tile loops with matching barrier counts (a barrier only counts arriving waves; written as one loop
+    // with a role branch inside, the allocator carries the accumulators through the producers' code and spills them).
+    // Division of labour per tile T (traced: with the producers staging both operands, the consumers idled 1.5-2.5 us per
+    // tile at the barrier):
+    //   producers   gradient operand of tile T + 1 (two-tensor BatchNorm-backward prologue, bias sums) -> LDS
+    //   consumers   request the x halo of tile T + 1, 72 MFMAs on tile T while those loads fly, then x prologue -> LDS
+    if (!consumer) {
+        // ---- producers --------------------------------------------------------------------------------------------------
+        struct GStage { u32x4 g1[4], g2[4]; };
+        GStage gA, gB;
+        const float gslope = a.gslope_p ? a.gslope_p[0] : a.gslope;
+        const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x8 bsum = zero8;                                          // bias gradient: this thread's 8 channels, its pixels
+        f32x8 qa, qb, qd, qs = zero8, qt = zero8;
 #pragma unroll
-        for (int k = 0; k < WT_XITEMS; ++k) {
-            const int px = (pt_ + k * 256) >> 3;
-            const int py = px / WT_IW, pxx = px - py * WT_IW;
-            const int iy = pty * WT_TH - 1 + py, ix = ptx * WT_TW - 1 + pxx;
-            const bool ok = px < WT_NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned voff = ok ? (unsigned)(((pn * a.H + iy) * a.W + ix) * 128 + oct * 16) : 0x80000000u;
-            sx[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0);
-            sok |= ok ? (1u << k) : 0u;
+        for (int j = 0; j < 8; ++j) {
+            qa[j] = a.qa[oct * 8 + j]; qb[j] = a.qb[oct * 8 + j]; qd[j] = a.qd[oct * 8 + j];
+            if (GPRO == SISR_PRO_BNACT_BWD) { qs[j] = a.qs[oct * 8 + j]; qt[j] = a.qt[oct * 8 + j]; }
         }
-    };
-    auto issue_g = [&](int half) {
-        const __amdgpu_buffer_rsrc_t r1 = bf_rsrc(a.g1, xbytes), r2 = bf_rsrc(a.g2, xbytes);
-        int pt_ = ptid;
-        asm volatile("" : "+v"(pt_));
-        const int oct = pt_ & 7;
+        const int grel0 = ((m0 >> 4) * a.W + (m0 & 15)) * 128 + oct * 16;  // tile pixel m0 + 32 k: two rows further down per item
+        const int glds0 = WT_XBYTES + m0 * WT_PS + oct * 16;
+        // (always executed, so that the tile loop below stays free of control flow around loads: past the last tile the
+        // offsets are out of range, which costs an instruction and no memory traffic.  With a branch around the loads the
+        // compiler's wait-count bookkeeping gives up at the merge and drains every load before the next commit.)
+        auto issue_g = [&](int T, GStage& st) {
+            const __amdgpu_buffer_rsrc_t r1 = bf_rsrc(a.g1, xbytes), r2 = bf_rsrc(a.g2, xbytes);
+            int ty, tx;
+            const unsigned origin = T < a.total ? tile_origin(T, ty, tx) : 0x80000000u;   // (a scalar select, not a branch)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int m = (pt_ + (2 * half + k) * 256) >> 3;               // tile pixel: row m >> 4, column m & 15
-            const unsigned voff = (unsigned)(((pn * a.H + pty * WT_TH + (m >> 4)) * a.W + ptx * WT_TW + (m & 15)) * 128 + oct * 16);
-            s1[2 * half + k] = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0);
-            s2[2 * half + k] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0);
-        }
-    };
-    auto commit_x = [&](int b) {
-        unsigned char* xi = lds + b * (WT_XBYTES + WT_DBYTES);
-        int pt_ = ptid;
-        asm volatile("" : "+v"(pt_));
-        const int oct = pt_ & 7;
-        // lrelu(a x + d) (a = 1, d = 0, slope = 1 degenerate to ACT / NONE), zero outside the image
-        const f32x8 ka = *reinterpret_cast<const f32x8*>(kst + oct * 8), kd = *reinterpret_cast<const f32x8*>(kst + 64 + oct * 8);
-#pragma unroll
-        for (int k = 0; k < WT_XITEMS; ++k) {
-            const int px = (pt_ + k * 256) >> 3;
-            const bool ok = (sok >> k) & 1u;
-            u32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v0 = __uint_as_float(sx[k][j] << 16), v1 = __uint_as_float(sx[k][j] & 0xFFFF0000u);
-                const float r0 = lrelu(ka[2 * j] * v0 + kd[2 * j], xslope), r1 = lrelu(ka[2 * j + 1] * v1 + kd[2 * j + 1], xslope);
-                o[j] = ok ? (f32_to_bf16_bits(r0) | (f32_to_bf16_bits(r1) << 16)) : 0u;
+            for (int k = 0; k < 4; ++k) {
+                const unsigned voff = origin + (unsigned)(grel0 + k * 2 * a.W * 128);
+                st.g1[k] = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0);
+                st.g2[k] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0);
             }
-            if (px < WT_NPIX) *reinterpret_cast<u32x4*>(xi + px * WT_PS + oct * 16) = o;
-        }
-    };
-    auto commit_g = [&](int b, int half) {
-        unsigned char* di = lds + b * (WT_XBYTES + WT_DBYTES) + WT_XBYTES;
-        int pt_ = ptid;
-        asm volatile("" : "+v"(pt_));
-        const int oct = pt_ & 7;
-        // BatchNorm backward (through the activation: sign of the re-derived pre-activation first, as a bit mask, so that
-        // at most 24 constant registers are live at a time)
-        unsigned zm = 0u;
-        if (GPRO == SISR_PRO_BNACT_BWD) {
-            const f32x8 ks = *reinterpret_cast<const f32x8*>(kst + 320 + oct * 8), kt = *reinterpret_cast<const f32x8*>(kst + 384 + oct * 8);
+        };
+        auto commit_g = [&](int b, const GStage& st) {
+            unsigned char* img = lds + b * (WT_XBYTES + WT_DBYTES);
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < 4; ++k) {
+                u32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const unsigned w = s2[2 * half + k][j];
-                    const float b0 = __uint_as_float(w << 16), b1 = __uint_as_float(w & 0xFFFF0000u);
-                    const unsigned p0 = ks[2 * j] * b0 + kt[2 * j] > 0.f ? 1u : 0u, p1 = ks[2 * j + 1] * b1 + kt[2 * j + 1] > 0.f ? 1u : 0u;
-                    zm |= (p0 | (p1 << 1)) << (k * 8 + 2 * j);
+                    const unsigned w1 = st.g1[k][j], w2 = st.g2[k][j];
+                    const float a0 = __uint_as_float(w1 << 16), a1 = __uint_as_float(w1 & 0xFFFF0000u);
+                    const float b0 = __uint_as_float(w2 << 16), b1 = __uint_as_float(w2 & 0xFFFF0000u);
+                    float g0 = a0, g1 = a1;
+                    if (GPRO == SISR_PRO_BNACT_BWD) {
+                        g0 = qs[2 * j] * b0 + qt[2 * j] > 0.f ? a0 : gslope * a0;
+                        g1 = qs[2 * j + 1] * b1 + qt[2 * j + 1] > 0.f ? a1 : gslope * a1;
+                    }
+                    const float r0 = qa[2 * j] * g0 + qb[2 * j] * b0 + qd[2 * j];
+                    const float r1 = qa[2 * j + 1] * g1 + qb[2 * j + 1] * b1 + qd[2 * j + 1];
+                    bsum[2 * j] += r0; bsum[2 * j + 1] += r1;
+                    o[j] = pack_bf16x2(r0, r1);
                 }
-        }
-        const f32x8 qa = *reinterpret_cast<const f32x8*>(kst + 128 + oct * 8), qb = *reinterpret_cast<const f32x8*>(kst + 192 + oct * 8),
-                    qd = *reinterpret_cast<const f32x8*>(kst + 256 + oct * 8);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int m = (pt_ + (2 * half + k) * 256) >> 3;
-            u32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned w1 = s1[2 * half + k][j], w2 = s2[2 * half + k][j];
-                const float a0 = __uint_as_float(w1 << 16), a1 = __uint_as_float(w1 & 0xFFFF0000u);
-                const float b0 = __uint_as_float(w2 << 16), b1 = __uint_as_float(w2 & 0xFFFF0000u);
-                float g0 = a0, g1 = a1;
-                if (GPRO == SISR_PRO_BNACT_BWD) {
-                    g0 = (zm >> (k * 8 + 2 * j)) & 1u ? a0 : gslope * a0;
-                    g1 = (zm >> (k * 8 + 2 * j + 1)) & 1u ? a1 : gslope * a1;
-                }
-                const float r0 = qa[2 * j] * g0 + qb[2 * j] * b0 + qd[2 * j];
-                const float r1 = qa[2 * j + 1] * g1 + qb[2 * j + 1] * b1 + qd[2 * j + 1];
-                bsum[2 * j] += r0; bsum[2 * j + 1] += r1;
-                o[j] = f32_to_bf16_bits(r0) | (f32_to_bf16_bits(r1) << 16);
+                *reinterpret_cast<u32x4*>(img + glds0 + k * 32 * WT_PS) = o;
             }
-            *reinterpret_cast<u32x4*>(di + m * WT_PS + oct * 16) = o;
-        }
-    };
-    auto produce = [&](int T, int b) {
-        issue_x(T);
-        issue_g(0);
-        issue_g(1);
-        commit_x(b);
-        commit_g(b, 0);
-        commit_g(b, 1);
-    };
-
-    // Two role-specific tile loops with matching barrier counts (a barrier only counts arriving waves): written as ONE
-    // loop with a role branch inside, the register allocator has to carry the consumers' 144 accumulator registers through
-    // the producers' code, and spills them.
-    float* sl = a.slab + (int64_t)blockIdx.x * a.slab_stride;
-    if (!consumer) {
+        };
+        // two register sets: the loads of tile T + 2 fly while tile T + 1 is transformed.  The loop is unrolled by two so
+        // that each set has a fixed name in each half.
         int T = blockIdx.x;
-        if (T < a.total) produce(T, 0);
+        issue_g(T, gA);
+        issue_g(T + gridDim.x, gB);
+        if (T < a.total) commit_g(0, gA);
+        WTTP(2);
         __syncthreads();
         int cur = 0;
-        for (; T < a.total; T += gridDim.x, cur ^= 1) {
-            const int Tn = T + gridDim.x;
-            if (Tn < a.total) produce(Tn, cur ^ 1);
+        [[maybe_unused]] int it = 0;
+        while (T < a.total) {
+            WTTP(4 + 6 * it);
+            issue_g(T + 2 * gridDim.x, gA);                       // gB holds tile T + grid
+            WTTP(5 + 6 * it);
+            if (T + (int)gridDim.x < a.total) commit_g(cur ^ 1, gB);
+            WTTP(8 + 6 * it);
             __syncthreads();      // the next tile's images are complete; the consumers have finished reading this one
+            WTTP(9 + 6 * it);
+            T += gridDim.x; cur ^= 1; ++it;
+            if (T >= a.total) break;
+            WTTP(4 + 6 * it);
+            issue_g(T + 2 * gridDim.x, gB);                       // gA holds tile T + grid
+            WTTP(5 + 6 * it);
+            if (T + (int)gridDim.x < a.total) commit_g(cur ^ 1, gA);
+            WTTP(8 + 6 * it);
+            __syncthreads();
+            WTTP(9 + 6 * it);
+            T += gridDim.x; cur ^= 1; ++it;
         }
-        if (a.bias_slab != nullptr) *reinterpret_cast<f32x8*>(lds + ptid * 32) = bsum;     // the images are free by now
+        if (a.bias_slab != nullptr) *reinterpret_cast<f32x8*>(lds + pt * 32) = bsum;     // the images are free by now
     } else {
+        // ---- consumers: the whole gradient of (32 output channels) x (9 taps x 32 input channels) in accumulators -----------
+        f32x16 acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        // transposing-read lane roles: 16-lane group grp -> (channel half grp & 1, pixel half grp >> 1 of the 16-pixel K
+        // step); inside the group lane 4q + p addresses (pixel row q, channels 4p .. 4p + 3)
+        const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+        const int rd_pix = (8 * (grp >> 1) + tq) * WT_PS + (16 * (grp & 1) + 4 * tp) * 2;
+        // x staging: rel[k] byte offset of item k from the tile's first pixel (negative in the top / left halo); flags: 5
+        // bits per item (halo row 0, row 9, column 0, column 17, beyond the halo) against the tile's edge pattern
+        u32x4 sx[WT_XITEMS];
+        unsigned bad = 0, xflags = 0;
+        int xrel[WT_XITEMS];
+#pragma unroll
+        for (int k = 0; k < WT_XITEMS; ++k) {
+            const int px = m0 + 32 * k;
+            const int py = px / WT_IW, pxx = px - py * WT_IW;
+            xrel[k] = ((py - 1) * a.W + (pxx - 1)) * 128 + oct * 16;
+            const unsigned f = (py == 0 ? 1u : 0u) | (py == WT_IH - 1 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == WT_IW - 1 ? 8u : 0u) |
+                               (px >= WT_NPIX ? 16u : 0u);
+            xflags |= f << (5 * k);
+        }
+        const int xlds0 = m0 * WT_PS + oct * 16;
+        const int tiles_y = a.per_img / a.tiles_x;
+        const float xslope = a.xpro != SISR_PRO_NONE ? (a.xslope_p ? a.xslope_p[0] : a.xslope) : 1.f;
+        const bool easy_slope = xslope >= 0.f && xslope <= 1.f;
+        auto issue_x = [&](int T) {
+            const __amdgpu_buffer_rsrc_t rx = bf_rsrc(a.x1, xbytes);
+            int ty, tx;
+            const unsigned origin = tile_origin(T, ty, tx);
+            const unsigned e = (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u) | 16u;
+            bad = xflags & (e * 0x02108421u);                                // edge pattern replicated over the 6 items
+#pragma unroll
+            for (int k = 0; k < WT_XITEMS; ++k) {
+                const bool ok = ((bad >> (5 * k)) & 31u) == 0u;
+                sx[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? origin + (unsigned)xrel[k] : 0x80000000u, 0, 0);
+            }
+        };
+        auto commit_x = [&](int b) {
+            unsigned char* dst0 = lds + b * (WT_XBYTES + WT_DBYTES) + xlds0;
+            if (easy_slope) wt_commit_x<true>(sx, bad, xflags, kst, oct, xslope, dst0);
+            else wt_commit_x<false>(sx, bad, xflags, kst, oct, xslope, dst0);
+        };
+        WTT(0);
+        if ((int)blockIdx.x < a.total) {
+            issue_x(blockIdx.x);
+            commit_x(0);
+        }
         __syncthreads();
-        int cur = 0;
-        for (int T = blockIdx.x; T < a.total; T += gridDim.x, cur ^= 1) {
+        int cur = 0, it = 0;
+        for (int T = blockIdx.x; T < a.total; T += gridDim.x, cur ^= 1, ++it) {
+            const int Tn = T + gridDim.x;
+            WTT(4 + 6 * it);
+            if (Tn < a.total) issue_x(Tn);
             // halo rows R = 0 .. 9: the three column shifts of row R against the gradient rows R, R - 1, R - 2
             const unsigned char* xb = lds + cur * (WT_XBYTES + WT_DBYTES) + rd_pix + 64 * gq;
             const unsigned char* db = lds + cur * (WT_XBYTES + WT_DBYTES) + WT_XBYTES + rd_pix + 64 * h;
@@ -250,8 +293,13 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
                         acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[kx], dyf[r], acc[ky * 3 + kx], 0, 0, 0);
                 }
             }
+            WTT(6 + 6 * it);
+            if (Tn < a.total) commit_x(cur ^ 1);
+            WTT(8 + 6 * it);
             __syncthreads();
+            WTT(9 + 6 * it);
         }
+        WTT(3);
         // one slab per workgroup: [chunk][tap][ci 32][64 co]
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -262,12 +310,13 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
         __syncthreads();
         if (tid < 64) {
             const float* bs = reinterpret_cast<const float*>(lds);
-            const int oct = tid >> 3, j = tid & 7;
+            const int o8 = tid >> 3, j = tid & 7;
             float s = 0.f;
-            for (int i = 0; i < 32; ++i) s += bs[(oct + 8 * i) * 8 + j];                 // fixed order: deterministic
+            for (int i = 0; i < 32; ++i) s += bs[(o8 + 8 * i) * 8 + j];                  // fixed order: deterministic
             a.bias_slab[(int64_t)blockIdx.x * a.slab_stride + tid] = s;
         }
     }
+    WTT(63);
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------
@@ -309,7 +358,7 @@ extern "C" int sisr_wgrad_bf16_slabs(const SisrWgradDesc* d) {
 
 template <int GPRO>
 static int launch_wtrunk(const WTrunkArgs& a, int grid, hipStream_t st) {
-    constexpr int lds_bytes = 2 * (WT_XBYTES + WT_DBYTES) + 7 * 64 * 4;
+    constexpr int lds_bytes = 2 * (WT_XBYTES + WT_DBYTES) + 2 * 64 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_trunk_kernel<GPRO>),

@@ -10,7 +10,8 @@ torch.cuda.synchronize()
 L = C.CDLL(os.environ['SISR_LIB'])
 slots = 128
 buf = np.zeros(512 * slots, dtype=np.uint64)
-assert L.sisr_ttrace_read(buf.ctypes.data_as(C.c_void_p), C.c_int(buf.size)) == 0
+reader = L.sisr_wttrace_read if os.environ.get('ROLE', 'fwd') == 'wgrad' else L.sisr_ttrace_read
+assert reader(buf.ctypes.data_as(C.c_void_p), C.c_int(buf.size)) == 0
 t = buf.reshape(512, slots).astype(np.int64) * 10e-3
 t = t[t[:, 0] > 0]
 t0 = t[:, 0].min()
