@@ -156,6 +156,10 @@ int sisr_conv2d_wgrad_bf16(const SisrWgradDesc *d, void *stream);
  * -- size `slab` (rows of slab_stride floats) and the reduction with it. */
 int sisr_wgrad_trunk_eligible(const SisrWgradDesc *d);
 int sisr_wgrad_bf16_slabs(const SisrWgradDesc *d);
+/* The same for the fp32 parity build: the trunk geometry with fp32 NHWC operands and H % 4 == 0, W % 16 == 0 runs on the
+ * persistent exact-fp32 kernel of wgrad_trunk_f32.hip behind sisr_conv2d_wgrad_f32 (one slab per workgroup). */
+int sisr_wgrad_trunk_f32_eligible(const SisrWgradDesc *d);
+int sisr_wgrad_f32_slabs(const SisrWgradDesc *d);
 int sisr_conv2d_wgrad_f32(const SisrWgradDesc *d, void *stream);
 /* out[i] = sum_s slab[s][i], i < elems (also used for the bias slabs) */
 int sisr_slab_reduce_f32(const float *slab, float *out, int32_t n_slabs, int64_t elems, void *stream);

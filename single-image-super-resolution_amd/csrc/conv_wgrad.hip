@@ -265,6 +265,9 @@ static int launch_wgrad(const SisrWgradDesc* d, hipStream_t st) {
     return 0;
 }
 
+extern "C" int sisr_wgrad_trunk_f32_eligible(const SisrWgradDesc* d);
+int sisr_wgrad_trunk_f32_launch(const SisrWgradDesc* d, hipStream_t st);      // wgrad_trunk_f32.hip
+
 extern "C" int sisr_conv2d_wgrad_f32(const SisrWgradDesc* d, void* stream) {
     if (!d || !d->x1 || !d->g1 || !d->slab) return SISR_E_BADARG;
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
@@ -273,6 +276,7 @@ extern "C" int sisr_conv2d_wgrad_f32(const SisrWgradDesc* d, void* stream) {
     if (d->grid_x <= 0 || d->lds_bytes <= 0 || d->lds_bytes > 160 * 1024 || d->KH * d->NT > WG_NACC)
         return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (sisr_wgrad_trunk_f32_eligible(d)) return sisr_wgrad_trunk_f32_launch(d, st);
     switch (d->KH * d->NT) {
         case 1: return launch_wgrad<1>(d, st);
         case 2: return launch_wgrad<2>(d, st);

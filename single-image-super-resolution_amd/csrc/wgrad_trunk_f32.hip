@@ -1,0 +1,289 @@
+// wgrad_trunk_f32.hip -- weight gradient of the generator's trunk geometry (3x3, 64 -> 64, stride 1, pad 1) in the
+// fp32 PARITY build: fp32 NHWC tensors, exact fp32 matrix instructions (v_mfma_f32_32x32x2_f32).  Reference path: the
+// autograd weight gradient of every nn.Conv2d(64, 64, 3, 1, 1) of model_generator.py:29-55 and :89-93.
+//
+//   dW[co][tap][ci] = sum over pixels p of dy[p][co] * x[p + tap][ci],      db[co] = sum_p dy[p][co]
+//
+// Same structure as the bf16 kernel of wgrad_trunk.hip (persistent workgroups, the whole 64 x 576 gradient in the
+// accumulators of four consumer waves across all of a workgroup's tiles, four producer waves staging the next tile
+// behind the MFMAs, role-specific tile loops), with what fp32 changes:
+//   * the matrix pipe is the binding resource by a wide margin (a 32x32x2 fp32 MFMA takes 64 cycles and moves 1/8 of a
+//     bf16 one's K): 288 MFMAs = 7.7 us per 4 x 16 pixel tile and wave against ~1 us of staging, so BOTH operands are
+//     staged by the producers and nothing about staging needs tuning;
+//   * tiles of 4 x 16 pixels: 2304 tiles = exactly 9 per CU at the benchmark size -- an MFMA-bound kernel pays for every
+//     idle CU of a partial round (8 x 16 tiles: 4.5 per CU);
+//   * an fp32 MFMA operand is ONE float per lane (lane = channel, lane half = pixel of the K pair), so plain pixel-major
+//     LDS images [pixel][64 floats] are read conflict-free with ds_read_b32 -- no transposing reads, no padding.
+// Slab layout as the generic fp32 kernel's (conv_wgrad.hip): [chunk][filter row][s * 33 + ci][64 co] + bias row, so the
+// reduction and un-packing kernels are shared.  One slab per workgroup.
+#include "sisr_dev.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+#define WF_TH 4
+#define WF_TW 16
+#define WF_IH (WF_TH + 2)
+#define WF_IW (WF_TW + 2)
+#define WF_NPIX (WF_IH * WF_IW)            // 108 halo pixels
+#define WF_PB 256                           // LDS bytes per pixel: 64 floats
+#define WF_XBYTES (WF_NPIX * WF_PB)         // 27648
+#define WF_DBYTES (WF_TH * WF_TW * WF_PB)   // 16384
+#define WF_XITEMS ((WF_NPIX * 16 + 255) / 256)   // 16-byte items (4 channels) per producer thread: 7
+#define WF_THREADS 512
+#define WF_PS 33                            // generic fp32 plan: krow = s * PS + ci
+#define WF_KROWP 100
+
+struct WTrunkF32Args {
+    const float *x1, *g1, *g2;
+    const float *pa, *pd;                   // x prologue (AFFINE_ACT)
+    const float* xslope_p; float xslope;
+    const float *qa, *qb, *qd, *qs, *qt;    // gradient prologue
+    const float* gslope_p; float gslope;
+    float *slab, *bias_slab;
+    int64_t slab_stride;
+    int N, H, W;
+    int tiles_x, per_img, total;
+    uint32_t m_tiles_x, m_per_img;
+    int xpro;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wf_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <int GPRO>
+__global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WTrunkF32Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];        // [2 buffers][x halo image | dy image]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int h = wave & 1, gq = (wave >> 1) & 1;             // consumer: output-channel half, input-channel chunk
+    const unsigned tbytes = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * 256u;
+    auto tile_origin = [&](int T, int& ty, int& tx) {
+        const int n = fdiv(T, a.m_per_img);
+        const int rem = T - n * a.per_img;
+        ty = fdiv(rem, a.m_tiles_x);
+        tx = rem - ty * a.tiles_x;
+        return (unsigned)(((n * a.H + ty * WF_TH) * a.W + tx * WF_TW) * 256);
+    };
+    float* sl = a.slab + (int64_t)blockIdx.x * a.slab_stride;
+
+    if (!consumer) {
+        // ---- producers: both operands of tile T + 1 while the consumers multiply tile T ------------------------------------
+        // item k of thread pt: pixel pt / 16 + 16 k (of the halo for x, of the tile for the gradient), channels 4 (pt % 16) ..
+        const int pt = tid & 255, quad = tid & 15, m0 = pt >> 4;
+        const int tiles_y = a.per_img / a.tiles_x;
+        const float xslope = a.xpro != SISR_PRO_NONE ? (a.xslope_p ? a.xslope_p[0] : a.xslope) : 1.f;
+        const float gslope = a.gslope_p ? a.gslope_p[0] : a.gslope;
+        const bool aff = a.xpro == SISR_PRO_AFFINE_ACT;
+        f32x4 ka, kd, qa, qb, qd, qs, qt;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ka[j] = aff ? a.pa[quad * 4 + j] : 1.f; kd[j] = aff ? a.pd[quad * 4 + j] : 0.f;
+            qa[j] = a.qa[quad * 4 + j]; qb[j] = a.qb[quad * 4 + j]; qd[j] = a.qd[quad * 4 + j];
+            qs[j] = GPRO == SISR_PRO_BNACT_BWD ? a.qs[quad * 4 + j] : 0.f;
+            qt[j] = GPRO == SISR_PRO_BNACT_BWD ? a.qt[quad * 4 + j] : 0.f;
+        }
+        f32x4 bsum = {0.f, 0.f, 0.f, 0.f};                    // bias gradient: this thread's 4 channels, its pixels
+        // tile-independent part of the x items: byte offset from the tile's first pixel, halo edge flags (4 bits per item:
+        // halo row 0, last row, column 0, last column; "beyond the halo" is folded into the validity of the last item)
+        int xrel[WF_XITEMS];
+        unsigned xflags = 0;
+#pragma unroll
+        for (int k = 0; k < WF_XITEMS; ++k) {
+            const int px = m0 + 16 * k;
+            const int py = px / WF_IW, pxx = px - py * WF_IW;
+            xrel[k] = ((py - 1) * a.W + (pxx - 1)) * 256 + quad * 16;
+            const unsigned f = px >= WF_NPIX ? 15u
+                               : (py == 0 ? 1u : 0u) | (py == WF_IH - 1 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == WF_IW - 1 ? 8u : 0u);
+            xflags |= f << (4 * k);
+        }
+        const bool last_beyond = m0 + 16 * (WF_XITEMS - 1) >= WF_NPIX;
+        const int grel0 = ((m0 >> 4) * a.W + (m0 & 15)) * 256 + quad * 16;   // tile pixel m0 + 16 k: one row further down per item
+        const int xlds0 = m0 * WF_PB + quad * 16, glds0 = WF_XBYTES + m0 * WF_PB + quad * 16;
+
+        auto produce = [&](int T, int b) {
+            const __amdgpu_buffer_rsrc_t rx = wf_rsrc(a.x1, tbytes), r1 = wf_rsrc(a.g1, tbytes), r2 = wf_rsrc(a.g2, tbytes);
+            int ty, tx;
+            const unsigned origin = tile_origin(T, ty, tx);
+            // every tile has an edge pattern; 15 marks "always outside" items (beyond the halo), which any non-zero mask hits
+            const unsigned e = (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u);
+            f32x4 sx[WF_XITEMS], s1[4], s2[4];
+            unsigned okm = 0;
+#pragma unroll
+            for (int k = 0; k < WF_XITEMS; ++k) {
+                const unsigned f = (xflags >> (4 * k)) & 15u;
+                const bool ok = f != 15u && (f & e) == 0u;
+                okm |= ok ? (1u << k) : 0u;
+                sx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? origin + (unsigned)xrel[k] : 0x80000000u, 0, 0));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned voff = origin + (unsigned)(grel0 + k * a.W * 256);
+                s1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0));
+                s2[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0));
+            }
+            unsigned char* img = lds + b * (WF_XBYTES + WF_DBYTES);
+            // x: lrelu(a x + d) (a = 1, d = 0, slope = 1 degenerate to ACT / NONE), zero outside the image
+#pragma unroll
+            for (int k = 0; k < WF_XITEMS; ++k) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (okm >> k) & 1u ? lrelu(ka[j] * sx[k][j] + kd[j], xslope) : 0.f;
+                if (k < WF_XITEMS - 1 || !last_beyond) *reinterpret_cast<f32x4*>(img + xlds0 + k * 16 * WF_PB) = o;
+            }
+            // gradient: BatchNorm backward (through the activation for BNACT_BWD); the bias gradient is summed on the way
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float g = s1[k][j];
+                    const float bx = s2[k][j];
+                    if (GPRO == SISR_PRO_BNACT_BWD) g = qs[j] * bx + qt[j] > 0.f ? g : gslope * g;
+                    o[j] = qa[j] * g + qb[j] * bx + qd[j];
+                }
+                bsum += o;
+                *reinterpret_cast<f32x4*>(img + glds0 + k * 16 * WF_PB) = o;
+            }
+        };
+
+        int T = blockIdx.x;
+        if (T < a.total) produce(T, 0);
+        __syncthreads();
+        int cur = 0;
+        for (; T < a.total; T += gridDim.x, cur ^= 1) {
+            const int Tn = T + gridDim.x;
+            if (Tn < a.total) produce(Tn, cur ^ 1);
+            __syncthreads();      // the next tile's images are complete; the consumers have finished reading this one
+        }
+        if (a.bias_slab != nullptr) *reinterpret_cast<f32x4*>(lds + pt * 16) = bsum;      // the images are free by now
+    } else {
+        // ---- consumers: (32 output channels) x (9 taps x 32 input channels) in accumulators, across all tiles ---------------
+        f32x16 acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        // operand lane roles (sisr_dev.h): A = x[pixel 2 s + kk][ci = l31], B = dy[pixel 2 s + kk][co = l31]
+        const int xoff = kk * WF_PB + (32 * gq + l31) * 4, doff = WF_XBYTES + kk * WF_PB + (32 * h + l31) * 4;
+        __syncthreads();
+        int cur = 0;
+        for (int T = blockIdx.x; T < a.total; T += gridDim.x, cur ^= 1) {
+            const unsigned char* xb = lds + cur * (WF_XBYTES + WF_DBYTES) + xoff;
+            const unsigned char* db = lds + cur * (WF_XBYTES + WF_DBYTES) + doff;
+            // halo row R, K step s (pixels 2 s, 2 s + 1 of the row): the three column shifts of the x row against the
+            // gradient rows R, R - 1, R - 2 -- every address is base + immediate
+#pragma unroll
+            for (int R = 0; R < WF_IH; ++R) {
+#pragma unroll
+                for (int s = 0; s < WF_TW / 2; ++s) {
+                    float xf[3], dyf[3];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) xf[kx] = *reinterpret_cast<const float*>(xb + (R * WF_IW + 2 * s + kx) * WF_PB);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int r = R - ky;
+                        if (r < 0 || r >= WF_TH) continue;
+                        dyf[ky] = *reinterpret_cast<const float*>(db + (r * WF_TW + 2 * s) * WF_PB);
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[kx], dyf[ky], acc[ky * 3 + kx], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // one slab per workgroup: [chunk gq][filter row ky][kx * 33 + ci][64 co]
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                sl[((gq * 3 + t / 3) * WF_KROWP + (t % 3) * WF_PS + mfma_row(i, lane)) * 64 + 32 * h + l31] = acc[t][i];
+    }
+    if (a.bias_slab != nullptr) {                       // ... and its bias row
+        __syncthreads();
+        if (tid < 64) {
+            const float* bs = reinterpret_cast<const float*>(lds);
+            const int q4 = tid >> 2, j = tid & 3;
+            float s = 0.f;
+            for (int i = 0; i < 16; ++i) s += bs[(q4 + 16 * i) * 4 + j];                  // fixed order: deterministic
+            a.bias_slab[(int64_t)blockIdx.x * a.slab_stride + tid] = s;
+        }
+    }
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------------
+static int wf_grid(const SisrWgradDesc* d) {
+    const int total = d->N * (d->H / WF_TH) * (d->W / WF_TW);
+    static int cus = 0;                         // (one process drives one GPU: queried once)
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 256;
+    }
+    const int rounds = (total + cus - 1) / cus;
+    return (total + rounds - 1) / rounds;       // equal shares
+}
+
+extern "C" int sisr_wgrad_trunk_f32_eligible(const SisrWgradDesc* d) {
+    const char* sw = getenv("SISR_TRUNK");                      // A/B switch: SISR_TRUNK=0 keeps the generic kernel
+    if (!d || (sw && sw[0] == '0')) return 0;
+    const char* sw2 = getenv("SISR_TRUNK_WGRAD");
+    if (sw2 && sw2[0] == '0') return 0;
+    if (d->Cin != 64 || d->Cout != 64 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
+    if (d->x_mode != SISR_X_NHWC || d->g_mode != SISR_X_NHWC || d->x_bf16 || d->g_bf16) return 0;
+    if (d->Ho != d->H || d->Wo != d->W || (d->H % WF_TH) || (d->W % WF_TW)) return 0;
+    if (d->CK != 32 || d->PS != WF_PS || d->KROWP != WF_KROWP || d->CoutPad != 64 || d->n_chunk != 2) return 0;
+    if ((int64_t)d->N * d->H * d->W * 256 >= (1ll << 31)) return 0;
+    if (d->N * (d->H / WF_TH) * (d->W / WF_TW) >= 65536) return 0;
+    const bool xp = d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT;
+    const bool gp = d->gpro_mode == SISR_PRO_BNBWD || d->gpro_mode == SISR_PRO_BNACT_BWD;
+    return xp && gp ? 1 : 0;
+}
+
+// slabs a launch of this descriptor writes (rows of `slab` at slab_stride)
+extern "C" int sisr_wgrad_f32_slabs(const SisrWgradDesc* d) {
+    if (!d) return SISR_E_BADARG;
+    return sisr_wgrad_trunk_f32_eligible(d) ? wf_grid(d) : d->n_slabs;
+}
+
+template <int GPRO>
+static int launch_wf(const WTrunkF32Args& a, int grid, hipStream_t st) {
+    constexpr int lds_bytes = 2 * (WF_XBYTES + WF_DBYTES);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_trunk_f32_kernel<GPRO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_trunk_f32_kernel<GPRO>), dim3(grid), dim3(WF_THREADS), lds_bytes, st, a);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+// called by sisr_conv2d_wgrad_f32 for eligible descriptors
+int sisr_wgrad_trunk_f32_launch(const SisrWgradDesc* d, hipStream_t st) {
+    if (operand_needs_x2(d->gpro_mode) && !d->g2) return SISR_E_BADARG;
+    if (d->pro_mode == SISR_PRO_AFFINE_ACT && (!d->pa || !d->pd)) return SISR_E_BADARG;
+    if (!d->qa || !d->qb || !d->qd || (d->gpro_mode == SISR_PRO_BNACT_BWD && (!d->qs || !d->qt))) return SISR_E_BADARG;
+    WTrunkF32Args a;
+    a.x1 = d->x1; a.g1 = d->g1; a.g2 = d->g2;
+    a.pa = d->pa; a.pd = d->pd; a.xslope_p = d->pro_slope_p; a.xslope = d->pro_slope;
+    a.qa = d->qa; a.qb = d->qb; a.qd = d->qd; a.qs = d->qs; a.qt = d->qt;
+    a.gslope_p = d->gpro_slope_p; a.gslope = d->gpro_slope;
+    a.slab = d->slab; a.bias_slab = d->bias_slab; a.slab_stride = d->slab_stride;
+    a.N = d->N; a.H = d->H; a.W = d->W;
+    a.tiles_x = d->W / WF_TW; a.per_img = (d->H / WF_TH) * a.tiles_x; a.total = d->N * a.per_img;
+    a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);
+    a.xpro = d->pro_mode;
+    const int grid = wf_grid(d);
+    if (d->gpro_mode == SISR_PRO_BNBWD) return launch_wf<SISR_PRO_BNBWD>(a, grid, st);
+    return launch_wf<SISR_PRO_BNACT_BWD>(a, grid, st);
+}

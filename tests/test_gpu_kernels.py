@@ -532,3 +532,65 @@ def test_trunk_kernel_weight_gradient_role(E, L, shape, xpro, gpro, monkeypatch)
         assert torch.equal(E.conv_wgrad(p, x_op, dy_op), red['1'])
     finally:
         E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('xpro,gpro', [('none', 'bnbwd'), ('act', 'bnact_bwd'), ('affine_act', 'bnbwd'), ('affine_act', 'bnact_bwd')])
+@pytest.mark.parametrize('shape', [(2, 12, 16), (3, 24, 48), (1, 96, 96)])
+def test_trunk_kernel_weight_gradient_role_fp32(E, L, shape, xpro, gpro, monkeypatch):
+    """wgrad_trunk_f32.hip (parity build: fp32 tensors, exact fp32 MFMA, persistent accumulators, 4 x 16 tiles) against
+    the generic fp32 weight-gradient kernel on the same lazy operands and against autograd: packed gradient, un-packed
+    weight gradient, bias gradient, bit-identical replay"""
+    n, h, w = shape
+    bc = lambda v: v[None, :, None, None]
+    x = _rand((n, 64, h, w), 111) * 2.0
+    g_in, c = _rand((n, 64, h, w), 112), _rand((n, 64, h, w), 113) * 2.0
+    wt = _rand((64, 64, 3, 3), 114, (1.0 / 576) ** 0.5)
+    b = _rand((64,), 115, 0.1)
+    sc, sh = _rand((64,), 116) * 0.5 + 1.0, _rand((64,), 117) * 0.3
+    qa, qb, qd = _rand((64,), 118) * 0.3 + 1.0, _rand((64,), 119) * 0.2, _rand((64,), 120) * 0.1
+    ks, kt = _rand((64,), 121) * 0.5 + 1.0, _rand((64,), 122) * 0.3
+    slope = torch.tensor([0.2])
+    xin = x
+    if xpro == 'act':
+        xin = F.leaky_relu(x, 0.2)
+    elif xpro == 'affine_act':
+        xin = F.leaky_relu(x * bc(sc) + bc(sh), 0.2)
+    gg = g_in
+    if gpro == 'bnact_bwd':
+        gg = torch.where(bc(ks) * c + bc(kt) > 0, g_in, 0.2 * g_in)
+    dy_ref = bc(qa) * gg + bc(qb) * c + bc(qd)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (F.conv2d(xin.double(), wr.double(), br.double(), padding=1) * dy_ref.double()).sum().backward()
+    E.set_precision('fp32')
+    ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 64, 3, 1, 1))
+    p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+    assert not p.kinds[2]
+    xd = nhwc(x).cuda()
+    if xpro == 'none':
+        x_op = E.Operand.plain(xd)
+    elif xpro == 'act':
+        x_op = E.Operand.act(xd, slope.cuda())
+    else:
+        x_op = E.Operand.affine_act(xd, sc.cuda(), sh.cuda(), slope.cuda())
+    gd, cd = nhwc(g_in).cuda(), nhwc(c).cuda()
+    kw = dict(pa=qa.cuda(), pb=qb.cuda(), pd=qd.cuda())
+    if gpro == 'bnact_bwd':
+        kw.update(ps=ks.cuda(), pt=kt.cuda(), slope=slope.cuda())
+    dy_op = E.Operand(gd, tuple(cd.shape), pro=L.PRO_BNACT_BWD if gpro == 'bnact_bwd' else L.PRO_BNBWD, x2=cd, **kw)
+    grads = {}
+    for sw in ('1', '0'):
+        monkeypatch.setenv('SISR_TRUNK_WGRAD', sw)
+        red = E.conv_wgrad(p, x_op, dy_op)
+        wg = E.WeightGradBatch()
+        wg.add(p, red)
+        grads[sw] = wg.run()[id(ref)] + (red,)
+    for k in (0, 1):
+        assert maxrel(grads['1'][k], grads['0'][k]) < 2e-5          # same fp32 products, different summation order
+    assert maxrel(grads['1'][0], wr.grad) < 1e-4, 'wgrad'
+    assert maxrel(grads['1'][1], br.grad) < 1e-4, 'bias grad'
+    monkeypatch.setenv('SISR_TRUNK_WGRAD', '1')
+    red2 = E.conv_wgrad(p, x_op, dy_op)
+    wg = E.WeightGradBatch()
+    wg.add(p, red2)
+    gw2, gb2 = wg.run()[id(ref)]
+    assert torch.equal(gw2, grads['1'][0]) and torch.equal(gb2, grads['1'][1])
