@@ -148,6 +148,15 @@ int sisr_conv2d_bf16(const SisrConvDesc *d, void *stream);
  * of `d` writes -- size those buffers with it (fill geometry, modes, storage flags, res / bnb pointers first). */
 int sisr_conv2d_trunk_eligible(const SisrConvDesc *d);
 int sisr_conv2d_bf16_parts(const SisrConvDesc *d);
+/* The fp32 parity build has its own persistent kernel for that geometry (fp32 NHWC in and out, H % 8 == 0, W % 16 == 0;
+ * conv_trunk_f32.hip, behind sisr_conv2d_f32): eligible returns 1 for the forward role, 2 for the data-gradient role;
+ * sisr_conv2d_f32_parts(d) = rows of stat_part / cnt_part the launch writes (one per pair of workgroups). */
+int sisr_conv2d_trunk_f32_eligible(const SisrConvDesc *d);
+int sisr_conv2d_f32_parts(const SisrConvDesc *d);
+/* rows of bnb_part (SisrConvDesc.bnb_*: fused BatchNorm-backward reductions) a data-gradient launch of `d` writes through
+ * sisr_conv2d_f32 -- one per workgroup of the persistent fp32 trunk kernel; 0 when that kernel does not take `d` (the
+ * generic fp32 kernel has no such epilogue: leave bnb_part NULL and run sisr_bn_bwd's own reduction). */
+int sisr_conv2d_f32_bnb_parts(const SisrConvDesc *d);
 int sisr_wgrad_plan_bf16(SisrWgradDesc *d, int32_t max_pixel_blocks);
 int sisr_conv2d_wgrad_bf16(const SisrWgradDesc *d, void *stream);
 /* The trunk geometry with bf16 NHWC operands (x prologue NONE / ACT / AFFINE_ACT, gradient prologue BNBWD /

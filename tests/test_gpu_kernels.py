@@ -594,3 +594,127 @@ def test_trunk_kernel_weight_gradient_role_fp32(E, L, shape, xpro, gpro, monkeyp
     wg.add(p, red2)
     gw2, gb2 = wg.run()[id(ref)]
     assert torch.equal(gw2, grads['1'][0]) and torch.equal(gb2, grads['1'][1])
+
+
+@pytest.mark.parametrize('pro', ['none', 'act', 'affine_act'])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 48), (1, 96, 96)])
+def test_trunk_kernel_fp32_forward_role(E, L, shape, pro, monkeypatch):
+    """conv_trunk_f32.hip (parity build: fp32 tensors, exact fp32 MFMA, weights of one cout half resident in LDS, producer /
+    consumer waves), forward role, against the generic fp32 kernel on the same operands and against F.conv2d in double:
+    output and the BatchNorm statistics merged from its per-stream partial rows"""
+    n, h, w = shape
+    x = _rand((n, 64, h, w), 131) * 2.0
+    wt = _rand((64, 64, 3, 3), 132, (1.0 / 576) ** 0.5 * 1.7)
+    b = _rand((64,), 133, 0.1)
+    sc, sh = _rand((64,), 134) * 0.5 + 1.0, _rand((64,), 135) * 0.3
+    slope = torch.tensor([0.2])
+    xin = x
+    if pro == 'act':
+        xin = F.leaky_relu(x, 0.2)
+    elif pro == 'affine_act':
+        xin = F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)
+    y_ref = F.conv2d(xin.double(), wt.double(), b.double(), padding=1)
+    E.set_precision('fp32')
+    ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 64, 3, 1, 1))
+    p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+    assert not p.kinds[0]
+    xd = nhwc(x).cuda()
+    if pro == 'none':
+        op = E.Operand.plain(xd)
+    elif pro == 'act':
+        op = E.Operand.act(xd, slope.cuda())
+    else:
+        op = E.Operand.affine_act(xd, sc.cuda(), sh.cuda(), slope.cuda())
+    res = {}
+    for sw in ('1', '0'):
+        monkeypatch.setenv('SISR_TRUNK_F32CONV', sw)
+        y, sp, cp = E.conv_forward(p, op, bias=ref.bias, stats=True)
+        res[sw] = (y, sp, cp)
+    assert res['1'][1].shape[0] <= min(res['0'][1].shape[0], 128)            # one row per pair of workgroups, not per tile
+    assert maxrel(nchw(res['1'][0]), y_ref) < 1e-5
+    assert maxrel(res['1'][0], res['0'][0]) < 1e-5
+    t1, m1, v1 = _merged_stats(res['1'][1], res['1'][2])
+    t0, m0, v0 = _merged_stats(res['0'][1], res['0'][2])
+    assert t1 == t0 == n * h * w
+    assert maxrel(m1, m0) < 1e-5 and maxrel(v1, v0) < 1e-5
+    assert maxrel(m1, y_ref.mean(dim=(0, 2, 3))) < 1e-5 and maxrel(v1, y_ref.var(dim=(0, 2, 3), unbiased=False)) < 1e-5
+    monkeypatch.setenv('SISR_TRUNK_F32CONV', '1')
+    y2, _, _ = E.conv_forward(p, op, bias=ref.bias, stats=True)
+    assert torch.equal(y2, res['1'][0])
+
+
+@pytest.mark.parametrize('pro,res', [('bnbwd', False), ('bnbwd', True), ('bnact_bwd', True), ('bnact_bwd', False)])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 48), (1, 96, 96)])
+def test_trunk_kernel_fp32_data_gradient_role(E, L, shape, pro, res, monkeypatch):
+    """conv_trunk_f32.hip, data-gradient role: two-tensor BatchNorm-backward prologue (with / without the activation),
+    skip gradient added in the epilogue -- against the generic fp32 kernel and against conv_transpose2d in double"""
+    n, h, w = shape
+    g_in, c = _rand((n, 64, h, w), 141), _rand((n, 64, h, w), 142) * 2.0
+    wt = _rand((64, 64, 3, 3), 143, (1.0 / 576) ** 0.5 * 1.7)
+    qa, qb, qd = _rand((64,), 144) * 0.3 + 1.0, _rand((64,), 145) * 0.2, _rand((64,), 146) * 0.1
+    ks, kt = _rand((64,), 147) * 0.5 + 1.0, _rand((64,), 148) * 0.3
+    slope = torch.tensor([0.2])
+    skip = _rand((n, 64, h, w), 149)
+    bc = lambda v: v[None, :, None, None]
+    gg = g_in
+    if pro == 'bnact_bwd':
+        gg = torch.where(bc(ks) * c + bc(kt) > 0, g_in, 0.2 * g_in)
+    dy_ref = bc(qa) * gg + bc(qb) * c + bc(qd)
+    out_ref = F.conv_transpose2d(dy_ref.double(), wt.double(), padding=1) + (skip.double() if res else 0.0)
+    E.set_precision('fp32')
+    ref = FakeConv(wt.cuda(), None, E.ConvGeom(64, 64, 3, 1, 1))
+    p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+    gd, cd = nhwc(g_in).cuda(), nhwc(c).cuda()
+    kw = dict(pa=qa.cuda(), pb=qb.cuda(), pd=qd.cuda())
+    if pro == 'bnact_bwd':
+        kw.update(ps=ks.cuda(), pt=kt.cuda(), slope=slope.cuda())
+    op = E.Operand(gd, tuple(cd.shape), pro=L.PRO_BNACT_BWD if pro == 'bnact_bwd' else L.PRO_BNBWD, x2=cd, **kw)
+    rd = nhwc(skip).cuda() if res else None
+    out = {}
+    for sw in ('1', '0'):
+        monkeypatch.setenv('SISR_TRUNK_F32CONV', sw)
+        out[sw] = E.conv_dgrad(p, op, res=rd)
+    assert maxrel(nchw(out['1']), out_ref) < 1e-5
+    assert maxrel(out['1'], out['0']) < 1e-5
+
+
+@pytest.mark.parametrize('pro,res,act', [('bnbwd', True, False), ('bnact_bwd', True, True), ('bnbwd', False, True)])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (1, 96, 96)])
+def test_trunk_kernel_fp32_fused_bn_backward_reductions(E, L, shape, pro, res, act, monkeypatch):
+    """conv_trunk_f32.hip, data-gradient role with bnb: the epilogue's per-workgroup rows of the next BatchNorm's backward
+    reductions, finalized, must equal the stand-alone reduction over the same gradient (fp32: 1e-5)"""
+    n, h, w = shape
+    g_in, c = _rand((n, 64, h, w), 151), _rand((n, 64, h, w), 152) * 2.0
+    wt = _rand((64, 64, 3, 3), 153, (1.0 / 576) ** 0.5 * 1.7)
+    qa, qb, qd = _rand((64,), 154) * 0.3 + 1.0, _rand((64,), 155) * 0.2, _rand((64,), 156) * 0.1
+    ks, kt = _rand((64,), 157) * 0.5 + 1.0, _rand((64,), 158) * 0.3
+    slope = torch.tensor([0.2])
+    skip = _rand((n, 64, h, w), 159)
+    xb = _rand((n, 64, h, w), 160) * 2.0
+    gamma, beta = _rand((64,), 161) + 1.5, _rand((64,), 162)
+    mean = xb.mean(dim=(0, 2, 3))
+    invstd = torch.rsqrt(xb.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    kb = torch.stack([gamma * invstd, beta - mean * gamma * invstd, mean, invstd]).cuda()
+    E.set_precision('fp32')
+    ref = FakeConv(wt.cuda(), None, E.ConvGeom(64, 64, 3, 1, 1))
+    p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+    assert E.can_fuse_bn_backward(p)
+    gd, cd = nhwc(g_in).cuda(), nhwc(c).cuda()
+    kw = dict(pa=qa.cuda(), pb=qb.cuda(), pd=qd.cuda())
+    if pro == 'bnact_bwd':
+        kw.update(ps=ks.cuda(), pt=kt.cuda(), slope=slope.cuda())
+    op = E.Operand(gd, tuple(cd.shape), pro=L.PRO_BNACT_BWD if pro == 'bnact_bwd' else L.PRO_BNBWD, x2=cd, **kw)
+    rd = nhwc(skip).cuda() if res else None
+    xd = nhwc(xb).cuda()
+    b_slope = slope.cuda() if act else None
+    g, part = E.conv_dgrad(p, op, res=rd, bnb=(xd, kb, b_slope))
+    assert part is not None and part.shape[0] <= 256
+    plain_g = E.conv_dgrad(p, op, res=rd)
+    assert torch.equal(g, plain_g)                                       # the fusion does not touch the gradient itself
+    fused = E.bn_backward(g, xd, kb, gamma.cuda(), slope=b_slope, part=part)
+    plain = E.bn_backward(g, xd, kb, gamma.cuda(), slope=b_slope)
+    for a_, b_ in zip(fused, plain):
+        if a_ is not None:
+            assert maxrel(a_, b_) < 2e-5
+    monkeypatch.setenv('SISR_TRUNK_F32CONV', '0')                        # generic kernel: no fusion, no rows
+    assert not E.can_fuse_bn_backward(p)
