@@ -236,6 +236,13 @@ def kernel_rooflines(device, precision, iters=40, only=None):
                  'wgrad': 'wgrad_trunk_kernel + slab_reduce_kernel (trunk 3x3 64->64)'}
         if os.environ.get('SISR_TRUNK_WGRAD', '1') == '0':
             names['wgrad'] = 'wgrad_mfma_bf16_kernel + slab_reduce_kernel (trunk 3x3 64->64)'
+    if precision == 'fp32' and os.environ.get('SISR_TRUNK', '1') != '0':
+        # fp32 tensors: the persistent exact-fp32 kernels (conv_trunk_f32.hip, wgrad_trunk_f32.hip)
+        if os.environ.get('SISR_TRUNK_F32CONV', '1') != '0':
+            names['fwd'] = 'conv_trunk_f32_kernel (trunk 3x3 64->64, forward role)'
+            names['dgrad'] = 'conv_trunk_f32_kernel (trunk 3x3 64->64, data-gradient role)'
+        if os.environ.get('SISR_TRUNK_WGRAD', '1') != '0':
+            names['wgrad'] = 'wgrad_trunk_f32_kernel + slab_reduce_kernel (trunk 3x3 64->64)'
     out_rec = {}
     if only is not None:                         # developer tools (tools/trace_conv.py, tools/prof_conv.py): one role
         roles = {r: v for r, v in roles.items() if r in only}

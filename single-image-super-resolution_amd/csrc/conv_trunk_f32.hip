@@ -136,39 +136,49 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
         const bool last_beyond = m0 + 32 * (CF_ITEMS - 1) >= CF_NPIX;
         const int ldso = (m0 * CF_PSF + quad * 4) * 4;
 
-        auto produce = [&](int j) {
+        // two staging register sets: the loads of stage j + 2 fly while stage j + 1 is transformed and written to LDS (a
+        // stage lasts ~4 us of MFMAs; a cold load round trip under a chip-wide load burst is not much shorter).  issue() is
+        // always executed -- past the last stage every offset is out of range, which costs an instruction and no traffic --
+        // so that the loop has no control flow around loads and the compiler's wait counts stay exact.
+        struct Stage { f32x4 s1[CF_ITEMS], s2[CF_ITEMS]; unsigned okm; };
+        Stage stA, stB;
+        auto issue = [&](int j, Stage& st) {
             const int T = stream + (j >> 1) * a.streams, q = j & 1;
             const __amdgpu_buffer_rsrc_t r1 = cf_rsrc(a.x1, tbytes), r2 = cf_rsrc(TWO ? a.x2 : a.x1, tbytes);
             int n, ty, tx;
             tile_coords(T, n, ty, tx);
             const unsigned origin = (unsigned)(((n * a.H + ty * CF_TH) * a.W + tx * CF_TW) * 256 + q * 128);
-            const unsigned e = (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u);
-            f32x4 s1[CF_ITEMS], s2[CF_ITEMS];
-            unsigned okm = 0;
+            // edge pattern of the tile; 15 = every item outside (stage past the end)
+            const unsigned e = j < n_stages ? (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u)
+                                            : 16u;
+            st.okm = 0;
 #pragma unroll
             for (int k = 0; k < CF_ITEMS; ++k) {
                 const unsigned f = (flags >> (4 * k)) & 15u;
-                const bool ok = f != 15u && (f & e) == 0u;
-                okm |= ok ? (1u << k) : 0u;
+                const bool ok = f != 15u && (f & e) == 0u && e != 16u;
+                st.okm |= ok ? (1u << k) : 0u;
                 const unsigned voff = ok ? origin + (unsigned)rel[k] : 0x80000000u;
-                s1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0));
-                if (TWO) s2[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0));
+                st.s1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0));
+                if (TWO) st.s2[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0));
             }
+        };
+        auto commit = [&](int j, const Stage& st) {
+            const int q = j & 1;
             float* img = reinterpret_cast<float*>(halo0 + (j & 1) * CF_HALO_BYTES + ldso);
             const f32x4 qa = ka[q], qb = kb[q], qd = kd[q], qs = ks[q], qt = kt[q];
 #pragma unroll
             for (int k = 0; k < CF_ITEMS; ++k) {
                 if (k == CF_ITEMS - 1 && last_beyond) break;
-                const bool ok = (okm >> k) & 1u;
+                const bool ok = (st.okm >> k) & 1u;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float v = s1[k][c];
+                    const float v = st.s1[k][c];
                     float r;
                     if (PRO == SISR_PRO_NONE) r = v;
                     else if (PRO == SISR_PRO_ACT) r = lrelu(v, slope);
                     else if (PRO == SISR_PRO_AFFINE_ACT) r = lrelu(qa[c] * v + qd[c], slope);
                     else {
-                        const float bx = s2[k][c];
+                        const float bx = st.s2[k][c];
                         float g = v;
                         if (PRO == SISR_PRO_BNACT_BWD) g = qs[c] * bx + qt[c] > 0.f ? v : slope * v;
                         r = qa[c] * g + qb[c] * bx + qd[c];
@@ -178,11 +188,21 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             }
         };
 
-        if (n_stages > 0) produce(0);
+        issue(0, stA);
+        issue(1, stB);
+        if (n_stages > 0) commit(0, stA);
         __syncthreads();
-        for (int j = 0; j < n_stages; ++j) {
-            if (j + 1 < n_stages) produce(j + 1);
+        // unrolled by two: each set has a fixed name in each half (stB holds stage j + 1 in the first)
+        int j = 0;
+        while (j < n_stages) {
+            issue(j + 2, stA);
+            if (j + 1 < n_stages) commit(j + 1, stB);
             __syncthreads();      // stage j + 1 is complete; the consumers have finished reading stage j
+            if (++j >= n_stages) break;
+            issue(j + 2, stB);
+            if (j + 1 < n_stages) commit(j + 1, stA);
+            __syncthreads();
+            ++j;
         }
     } else {
         // ---- consumers: wave w = tile rows 2 w, 2 w + 1 (32 pixels) x this workgroup's 32 couts -------------------------------

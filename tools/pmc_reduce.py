@@ -5,8 +5,9 @@ import csv, glob, json, os, sys
 d = sys.argv[1]
 # the kernel a role launches: the persistent trunk kernels when they take the geometry, else the generic ones; the
 # weight-gradient role also launches the slab reduction, whose traffic is added to the role's
-KERNEL = {'fwd': ('conv_trunk_fwd_kernel', 'conv_mfma_bf16_kernel'), 'dgrad': ('conv_trunk_bwd_kernel', 'conv_mfma_bf16_kernel'),
-          'wgrad': ('wgrad_trunk_kernel', 'wgrad_mfma_bf16_kernel')}
+KERNEL = {'fwd': ('conv_trunk_fwd_kernel', 'conv_trunk_f32_kernel', 'conv_mfma_bf16_kernel', 'conv_mfma_f32_kernel'),
+          'dgrad': ('conv_trunk_bwd_kernel', 'conv_trunk_f32_kernel', 'conv_mfma_bf16_kernel', 'conv_mfma_f32_kernel'),
+          'wgrad': ('wgrad_trunk_kernel', 'wgrad_trunk_f32_kernel', 'wgrad_mfma_bf16_kernel', 'wgrad_mfma_f32_kernel')}
 EXTRA = {'wgrad': 'slab_reduce_kernel'}
 out = {}
 for role in ('fwd', 'dgrad', 'wgrad'):
@@ -44,7 +45,8 @@ for role in ('fwd', 'dgrad', 'wgrad'):
 json.dump(out, open(os.path.join(d, 'pmc_per_launch.json'), 'w'), indent=1)
 # the file bench.py reads its `traffic` from (profiles/r02_traffic.json)
 commit = os.environ.get('SISR_COMMIT', '?')
-json.dump({'bf16_' + role: {'traffic_bytes_per_launch': rec['traffic_bytes_per_launch'], 'kernel': rec.get('kernel'), 'commit': commit}
+fam = 'f32' if os.environ.get('SISR_PRECISION', 'bf16') == 'fp32' else 'bf16'
+json.dump({fam + '_' + role: {'traffic_bytes_per_launch': rec['traffic_bytes_per_launch'], 'kernel': rec.get('kernel'), 'commit': commit}
            for role, rec in out.items() if 'traffic_bytes_per_launch' in rec}, open(os.path.join(d, 'traffic.json'), 'w'), indent=1)
 for role, rec in out.items():
     print(role, json.dumps(rec.get('per_wave', {})), 'traffic MB %.1f' % (rec.get('traffic_bytes_per_launch', 0) / 1e6))
