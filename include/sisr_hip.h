@@ -41,7 +41,11 @@ enum {
     SISR_PRO_BNACT_BWD = 4,   /* z = ps[c]*x2+pt[c]; g = z>0 ? x1 : slope*x1;
                                  v = pa[c]*g + pb[c]*x2 + pd[c]       act' then BatchNorm bwd   */
     SISR_PRO_ACT_BWD = 5,     /* v = x2>0 ? x1 : slope*x1             act' (x2 = pre-activation)*/
-    SISR_PRO_TANH_BWD = 6     /* v = x1*(1 - x2*x2)                   tanh' (x2 = tanh output)  */
+    SISR_PRO_TANH_BWD = 6,    /* v = x1*(1 - x2*x2)                   tanh' (x2 = tanh output)  */
+    SISR_PRO_RES_AFFINE = 7   /* v = lrelu(x1, slope) + (pa[c]*x2 + pd[c])   residual-block skip sum x + BN2(c2)
+                                 (model_generator.py:19) formed in the consuming conv's staging; the sum is also
+                                 stored to x_out once per pixel.  Persistent trunk kernels only (forward role):
+                                 the generic kernels return SISR_E_UNSUPPORTED. */
 };
 enum { SISR_X_NHWC = 0, SISR_X_NCHW = 1, SISR_X_NHWC_UNSHUFFLE2 = 2 };
 enum { SISR_Y_NHWC = 0, SISR_Y_NCHW = 1, SISR_Y_NHWC_SHUFFLE2 = 2 };
@@ -84,6 +88,7 @@ typedef struct SisrConvDesc {
     const float *bnb_x, *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
     const float *bnb_slope_p;
     float *bnb_part;
+    float *x_out;                            /* SISR_PRO_RES_AFFINE: the materialised operand, layout / type of x1 */
     int32_t N, H, W, Cin;                    /* logical input                                 */
     int32_t Ho, Wo, Cout;                    /* logical output grid                           */
     int32_t KH, KW, stride, pad_y, pad_x;

@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('SISR_LIB') or os.path.join(CSRC, 'libsisr_hip.so')      # SISR_LIB: developer builds
 
 # enums (sisr_hip.h)
-PRO_NONE, PRO_ACT, PRO_AFFINE_ACT, PRO_BNBWD, PRO_BNACT_BWD, PRO_ACT_BWD, PRO_TANH_BWD = range(7)
+PRO_NONE, PRO_ACT, PRO_AFFINE_ACT, PRO_BNBWD, PRO_BNACT_BWD, PRO_ACT_BWD, PRO_TANH_BWD, PRO_RES_AFFINE = range(8)
 X_NHWC, X_NCHW, X_UNSHUFFLE2 = range(3)
 Y_NHWC, Y_NCHW, Y_SHUFFLE2 = range(3)
 EPI_NONE, EPI_TANH = range(2)
@@ -33,7 +33,7 @@ class ConvPlan(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = ([(n, _f) for n in ('x1', 'x2', 'pa', 'pb', 'pd', 'ps', 'pt', 'wpk', 'bias', 'res', 'y',
                                    'stat_part', 'cnt_part', 'bnb_x', 'bnb_scale', 'bnb_shift', 'bnb_mean',
-                                   'bnb_invstd', 'bnb_slope_p', 'bnb_part')] +
+                                   'bnb_invstd', 'bnb_slope_p', 'bnb_part', 'x_out')] +
                 [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride',
                                      'pad_y', 'pad_x', 'x_mode', 'pro_mode')] +
                 [('pro_slope_p', _f), ('pro_slope', _f32)] +

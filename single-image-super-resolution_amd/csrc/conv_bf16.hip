@@ -670,6 +670,7 @@ extern "C" int sisr_conv2d_bf16(const SisrConvDesc* d, void* stream) {
         if (d->stat_part && !d->cnt_part) return SISR_E_BADARG;
         return sisr_conv2d_trunk_launch(d, st);
     }
+    if (d->pro_mode == SISR_PRO_RES_AFFINE) return SISR_E_UNSUPPORTED;      // persistent trunk kernels only
     // TAG only names the symbol (same code): 1 = the generator's trunk geometry in its forward role (BatchNorm
     // statistics epilogue) -- the launch bench.py's roofline probe times --, 2 = the trunk geometry in its other
     // roles (data gradients), 0 = everything else; profiles then report the roles separately

@@ -66,6 +66,7 @@ extern "C" int sisr_ttrace_read(void* dst, int n_u64) {
 
 struct TrunkArgs {
     const void *x1, *x2;                  // input operand(s), bf16 NHWC [N][H][W][64]
+    void* x_out;                          // skip-sum prologue: the materialised operand
     const float *pa, *pb, *pd, *ps, *pt;  // per-channel prologue constants
     const float* slope_p; float slope;
     const void* wpk;                      // bf16 image [2 chunks][64 couts][9 taps][32 cin]
@@ -125,11 +126,14 @@ __device__ __forceinline__ u32x4 trunk_apply8(u32x4 a, u32x4 b, const f32x8& ka,
     for (int j = 0; j < 4; ++j) {
         const float a0 = __uint_as_float(a[j] << 16), a1 = __uint_as_float(a[j] & 0xFFFF0000u);
         float b0 = 0.f, b1 = 0.f;
-        if (PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD) {
+        if (PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD || PRO == SISR_PRO_RES_AFFINE) {
             b0 = __uint_as_float(b[j] << 16); b1 = __uint_as_float(b[j] & 0xFFFF0000u);
         }
         float r0, r1;
         if (PRO == SISR_PRO_ACT) { r0 = lrelu_t<EASY>(a0, slope); r1 = lrelu_t<EASY>(a1, slope); }
+        else if (PRO == SISR_PRO_RES_AFFINE) {                 // as sisr_eltwise_res_affine: lrelu(x1) + (a x2 + d)
+            r0 = lrelu_t<EASY>(a0, slope) + (ka[2 * j] * b0 + kd[2 * j]); r1 = lrelu_t<EASY>(a1, slope) + (ka[2 * j + 1] * b1 + kd[2 * j + 1]);
+        }
         else if (PRO == SISR_PRO_AFFINE_ACT) {
             r0 = lrelu_t<EASY>(ka[2 * j] * a0 + kd[2 * j], slope); r1 = lrelu_t<EASY>(ka[2 * j + 1] * a1 + kd[2 * j + 1], slope);
         } else if (PRO == SISR_PRO_BNBWD) {
@@ -187,8 +191,11 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x8 ka = zero8, kd = zero8;
     float slope = 1.f;
-    u32x4 sreg[TK_ITEMS];
-    unsigned sok = 0;
+    // a staging set: the raw items of one tile (x2 only for the two-tensor skip-sum prologue), its "outside" mask and
+    // the byte offset of its first pixel (the skip-sum prologue stores the materialised sum back through it)
+    constexpr bool TWO = PRO == SISR_PRO_RES_AFFINE;
+    struct Stage { u32x4 a[TK_ITEMS], b[TWO ? TK_ITEMS : 1]; unsigned bad, origin; };
+    Stage stA, stB;
     HaloMap hm;
     bool easy_slope = true;
 
@@ -214,44 +221,48 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
         slope = a.slope_p ? a.slope_p[0] : a.slope;
         easy_slope = slope >= 0.f && slope <= 1.f;
         halo_map_init(hm, ptid, a.W);
-        if (PRO == SISR_PRO_AFFINE_ACT) {
+        if (PRO == SISR_PRO_AFFINE_ACT || TWO) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { ka[j] = a.pa[oct * 8 + j]; kd[j] = a.pd[oct * 8 + j]; }
         }
     };
     // two staging register sets: the loads of tile T + 2 are in flight while tile T + 1 is transformed and written to
     // LDS, so the producers never sit out a full memory latency (they are the critical path otherwise)
-    u32x4 sreg2[TK_ITEMS];
-    unsigned sok2 = 0;
     const int tiles_y = a.per_img / a.tiles_x;
-    auto issue = [&](int T, u32x4 (&sr)[TK_ITEMS], unsigned& bad) {
-        const __amdgpu_buffer_rsrc_t rx = bf_rsrc(a.x1, xbytes);
+    auto issue = [&](int T, Stage& st) {
+        const __amdgpu_buffer_rsrc_t rx = bf_rsrc(a.x1, xbytes), rx2 = bf_rsrc(TWO ? a.x2 : a.x1, xbytes);
         int n, ty, tx;
         tile_coords(T, n, ty, tx);
-        const unsigned origin = (unsigned)(((n * a.H + ty * TK_TH) * a.W + tx * TK_TW) * 128);
+        st.origin = (unsigned)(((n * a.H + ty * TK_TH) * a.W + tx * TK_TW) * 128);
         // (always executed, so that the tile loop stays free of control flow around loads: past the last tile every
         // item is "outside", which costs an instruction and no memory traffic.  With a branch around the loads the
         // compiler's wait-count bookkeeping gives up at the merge and drains every load before the next commit.)
-        bad = T < a.total ? hm.flags & tile_edge_mask(ty, tx, tiles_y, a.tiles_x) : 0xFFFFFFFFu;
+        st.bad = T < a.total ? hm.flags & tile_edge_mask(ty, tx, tiles_y, a.tiles_x) : 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
-            const bool ok = ((bad >> (5 * k)) & 31u) == 0u;
-            sr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? origin + (unsigned)hm.rel[k] : 0x80000000u, 0, 0);
+            const bool ok = ((st.bad >> (5 * k)) & 31u) == 0u;
+            const unsigned voff = ok ? st.origin + (unsigned)hm.rel[k] : 0x80000000u;
+            st.a[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0);
+            if (TWO) st.b[k] = __builtin_amdgcn_raw_buffer_load_b128(rx2, voff, 0, 0);
         }
     };
-    auto commit_t = [&](auto easy, unsigned char* buf, const u32x4 (&sr)[TK_ITEMS], unsigned bad) {
+    auto commit_t = [&](auto easy, unsigned char* buf, const Stage& st) {
         constexpr bool EASY = decltype(easy)::value;
+        const __amdgpu_buffer_rsrc_t ro = bf_rsrc(TWO ? a.x_out : a.x1, xbytes);
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
-            const bool ok = ((bad >> (5 * k)) & 31u) == 0u;
-            const u32x4 v = trunk_apply8<PRO, EASY>(sr[k], sr[k], ka, ka, kd, ka, ka, slope, ok);
+            const bool ok = ((st.bad >> (5 * k)) & 31u) == 0u;
+            const u32x4 v = trunk_apply8<PRO, EASY>(st.a[k], st.b[TWO ? k : 0], ka, ka, kd, ka, ka, slope, ok);
             // (only the last item of a thread can lie beyond the 180 halo pixels)
             if (k < TK_ITEMS - 1 || !((hm.flags >> (5 * k + 4)) & 1u)) *reinterpret_cast<u32x4*>(buf + hm.ldso[k]) = v;
+            // skip-sum prologue: the tiles partition the image, so the items of a tile's own 8 x 16 pixels (no halo flag
+            // set) store every pixel of the materialised sum exactly once
+            if (TWO && ((hm.flags >> (5 * k)) & 31u) == 0u) __builtin_amdgcn_raw_buffer_store_b128(v, ro, st.origin + (unsigned)hm.rel[k], 0, 0);
         }
     };
-    auto commit = [&](unsigned char* buf, const u32x4 (&sr)[TK_ITEMS], unsigned bad) {
-        if (easy_slope) commit_t(std::true_type{}, buf, sr, bad);
-        else commit_t(std::false_type{}, buf, sr, bad);
+    auto commit = [&](unsigned char* buf, const Stage& st) {
+        if (easy_slope) commit_t(std::true_type{}, buf, st);
+        else commit_t(std::false_type{}, buf, st);
     };
     __bf16* my_out = out_img + (wave & 3) * (32 * TK_YS);
     const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
@@ -263,28 +274,28 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
         // ---- producers: tile T + 1 into the other buffer while the consumers work on tile T ------------------------------
         init_producer();
         int T = blockIdx.x;
-        issue(T, sreg, sok);
-        issue(T + gridDim.x, sreg2, sok2);
-        if (T < a.total) commit(lds, sreg, sok);
+        issue(T, stA);
+        issue(T + gridDim.x, stB);
+        if (T < a.total) commit(lds, stA);
         TTP(2);
         __syncthreads();
-        // unrolled by two: each staging set has a fixed name in each half (sreg2 holds tile T + grid in the first)
+        // unrolled by two: each staging set has a fixed name in each half (stB holds tile T + grid in the first)
         int cur = 0;
         [[maybe_unused]] int it = 0;
         while (T < a.total) {
             TTP(4 + 6 * it);
-            issue(T + 2 * gridDim.x, sreg, sok);
+            issue(T + 2 * gridDim.x, stA);
             TTP(5 + 6 * it);
-            if (T + (int)gridDim.x < a.total) commit(lds + (cur ^ 1) * TK_HALO_BYTES, sreg2, sok2);
+            if (T + (int)gridDim.x < a.total) commit(lds + (cur ^ 1) * TK_HALO_BYTES, stB);
             TTP(8 + 6 * it);
             __syncthreads();
             TTP(9 + 6 * it);
             T += gridDim.x; cur ^= 1; ++it;
             if (T >= a.total) break;
             TTP(4 + 6 * it);
-            issue(T + 2 * gridDim.x, sreg2, sok2);
+            issue(T + 2 * gridDim.x, stB);
             TTP(5 + 6 * it);
-            if (T + (int)gridDim.x < a.total) commit(lds + (cur ^ 1) * TK_HALO_BYTES, sreg, sok);
+            if (T + (int)gridDim.x < a.total) commit(lds + (cur ^ 1) * TK_HALO_BYTES, stA);
             TTP(8 + 6 * it);
             __syncthreads();
             TTP(9 + 6 * it);
@@ -706,7 +717,8 @@ extern "C" int sisr_conv2d_trunk_eligible(const SisrConvDesc* d) {
     if (d->epi_act != SISR_EPI_NONE) return 0;
     if ((int64_t)d->N * d->H * d->W * 128 >= (1ll << 31)) return 0;
     if (d->N * (d->H / TK_TH) * (d->W / TK_TW) >= 65536) return 0;
-    const bool fwd_pro = d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT;
+    const bool fwd_pro = d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT ||
+                         (d->pro_mode == SISR_PRO_RES_AFFINE && d->x2 && d->x_out && d->pa && d->pd);
     if (fwd_pro && !d->res && !d->bnb_part) return 1;           // forward role
     const bool bwd_pro = d->pro_mode == SISR_PRO_BNBWD || d->pro_mode == SISR_PRO_BNACT_BWD;
     if (bwd_pro && !d->stat_part && !d->bias && (!d->res || d->res_bf16) && (!d->bnb_part || d->bnbx_bf16)) return 2;   // data-gradient role
@@ -754,7 +766,7 @@ static int launch_trunk_bwd(const TrunkArgs& a, int grid, bool images, hipStream
 // called by sisr_conv2d_bf16 for eligible descriptors
 int sisr_conv2d_trunk_launch(const SisrConvDesc* d, hipStream_t st) {
     TrunkArgs a;
-    a.x1 = d->x1; a.x2 = d->x2; a.pa = d->pa; a.pb = d->pb; a.pd = d->pd; a.ps = d->ps; a.pt = d->pt;
+    a.x1 = d->x1; a.x2 = d->x2; a.x_out = d->x_out; a.pa = d->pa; a.pb = d->pb; a.pd = d->pd; a.ps = d->ps; a.pt = d->pt;
     a.slope_p = d->pro_slope_p; a.slope = d->pro_slope;
     a.wpk = d->wpk; a.bias = d->bias; a.y = d->y; a.stat_part = d->stat_part; a.cnt_part = d->cnt_part;
     a.N = d->N; a.H = d->H; a.W = d->W;
@@ -771,6 +783,7 @@ int sisr_conv2d_trunk_launch(const SisrConvDesc* d, hipStream_t st) {
         case SISR_PRO_NONE: return launch_trunk_fwd<SISR_PRO_NONE>(a, grid, st);
         case SISR_PRO_ACT: return launch_trunk_fwd<SISR_PRO_ACT>(a, grid, st);
         case SISR_PRO_AFFINE_ACT: return launch_trunk_fwd<SISR_PRO_AFFINE_ACT>(a, grid, st);
+        case SISR_PRO_RES_AFFINE: return launch_trunk_fwd<SISR_PRO_RES_AFFINE>(a, grid, st);
     }
     return SISR_E_UNSUPPORTED;
 }

@@ -17,6 +17,8 @@
 // The two workgroups of a cout pair walk the same pixel tiles and share one statistics row: each writes its 32 channels.
 #include "sisr_dev.h"
 
+typedef unsigned cf_u32x4 __attribute__((ext_vector_type(4)));
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -36,6 +38,7 @@
 
 struct CTrunkF32Args {
     const float *x1, *x2;
+    float* x_out;                         // skip-sum prologue: the materialised operand
     const float *pa, *pb, *pd, *ps, *pt;
     const float* slope_p; float slope;
     const float* wpk;
@@ -70,7 +73,8 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
     const int l31 = lane & 31, kk = lane >> 5;
     const int hc = blockIdx.x & 1, stream = blockIdx.x >> 1;   // output-channel half, pixel-tile stream
     const unsigned tbytes = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * 256u;
-    constexpr bool TWO = PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD;
+    constexpr bool TWO = PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD || PRO == SISR_PRO_RES_AFFINE;
+    constexpr bool SUM = PRO == SISR_PRO_RES_AFFINE;          // skip-sum prologue: lrelu(x1) + (a x2 + d), stored back once
     auto tile_coords = [&](int T, int& n, int& ty, int& tx) {
         n = fdiv(T, a.m_per_img);
         const int rem = T - n * a.per_img;
@@ -118,7 +122,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
                 const int c = q * 32 + quad * 4 + j;
                 ka[q][j] = (PRO == SISR_PRO_AFFINE_ACT || TWO) ? a.pa[c] : 1.f;
                 kd[q][j] = (PRO == SISR_PRO_AFFINE_ACT || TWO) ? a.pd[c] : 0.f;
-                kb[q][j] = TWO ? a.pb[c] : 0.f;
+                kb[q][j] = (TWO && !SUM) ? a.pb[c] : 0.f;
                 ks[q][j] = PRO == SISR_PRO_BNACT_BWD ? a.ps[c] : 0.f;
                 kt[q][j] = PRO == SISR_PRO_BNACT_BWD ? a.pt[c] : 0.f;
             }
@@ -140,7 +144,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
         // stage lasts ~4 us of MFMAs; a cold load round trip under a chip-wide load burst is not much shorter).  issue() is
         // always executed -- past the last stage every offset is out of range, which costs an instruction and no traffic --
         // so that the loop has no control flow around loads and the compiler's wait counts stay exact.
-        struct Stage { f32x4 s1[CF_ITEMS], s2[CF_ITEMS]; unsigned okm; };
+        struct Stage { f32x4 s1[CF_ITEMS], s2[CF_ITEMS]; unsigned okm, origin; };
         Stage stA, stB;
         auto issue = [&](int j, Stage& st) {
             const int T = stream + (j >> 1) * a.streams, q = j & 1;
@@ -152,6 +156,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             const unsigned e = j < n_stages ? (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u)
                                             : 16u;
             st.okm = 0;
+            st.origin = origin;
 #pragma unroll
             for (int k = 0; k < CF_ITEMS; ++k) {
                 const unsigned f = (flags >> (4 * k)) & 15u;
@@ -165,26 +170,31 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
         auto commit = [&](int j, const Stage& st) {
             const int q = j & 1;
             float* img = reinterpret_cast<float*>(halo0 + (j & 1) * CF_HALO_BYTES + ldso);
-            const f32x4 qa = ka[q], qb = kb[q], qd = kd[q], qs = ks[q], qt = kt[q];
+            // (selects, not dynamically indexed arrays: those would live in scratch)
+            const f32x4 qa = q ? ka[1] : ka[0], qb = q ? kb[1] : kb[0], qd = q ? kd[1] : kd[0], qs = q ? ks[1] : ks[0], qt = q ? kt[1] : kt[0];
+            const __amdgpu_buffer_rsrc_t ro = cf_rsrc(SUM ? a.x_out : a.x1, tbytes);
 #pragma unroll
             for (int k = 0; k < CF_ITEMS; ++k) {
                 if (k == CF_ITEMS - 1 && last_beyond) break;
                 const bool ok = (st.okm >> k) & 1u;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                auto value = [&](int c) {
                     const float v = st.s1[k][c];
-                    float r;
-                    if (PRO == SISR_PRO_NONE) r = v;
-                    else if (PRO == SISR_PRO_ACT) r = lrelu(v, slope);
-                    else if (PRO == SISR_PRO_AFFINE_ACT) r = lrelu(qa[c] * v + qd[c], slope);
-                    else {
-                        const float bx = st.s2[k][c];
-                        float g = v;
-                        if (PRO == SISR_PRO_BNACT_BWD) g = qs[c] * bx + qt[c] > 0.f ? v : slope * v;
-                        r = qa[c] * g + qb[c] * bx + qd[c];
-                    }
-                    img[k * 32 * CF_PSF + c] = ok ? r : 0.f;             // the halo is zero AFTER the transform
-                }
+                    if (PRO == SISR_PRO_NONE) return v;
+                    if (PRO == SISR_PRO_ACT) return lrelu(v, slope);
+                    if (PRO == SISR_PRO_AFFINE_ACT) return lrelu(qa[c] * v + qd[c], slope);
+                    if (SUM) return lrelu(v, slope) + (qa[c] * st.s2[k][c] + qd[c]);      // as sisr_eltwise_res_affine
+                    const float bx = st.s2[k][c];
+                    float g = v;
+                    if (PRO == SISR_PRO_BNACT_BWD) g = qs[c] * bx + qt[c] > 0.f ? v : slope * v;
+                    return qa[c] * g + qb[c] * bx + qd[c];
+                };
+                const f32x4 osum = {value(0), value(1), value(2), value(3)};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) img[k * 32 * CF_PSF + c] = ok ? osum[c] : 0.f;   // the halo is zero AFTER the transform
+                // skip-sum prologue: the tile's own 8 x 16 pixels (no halo flag) store the materialised sum, once per pixel
+                // and channel half -- by the workgroup of cout half 0 (its partner stages the same tiles)
+                if (SUM && hc == 0 && ((flags >> (4 * k)) & 15u) == 0u)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cf_u32x4, osum), ro, st.origin + (unsigned)rel[k], 0, 0);
             }
         };
 
@@ -413,7 +423,8 @@ extern "C" int sisr_conv2d_trunk_f32_eligible(const SisrConvDesc* d) {
     if (d->plan.CK != 32 || d->plan.PS != CF_PS || d->plan.KROWP != CF_KROWP || d->plan.CoutPad != 64 || d->plan.n_chunk != 2) return 0;
     if ((int64_t)d->N * d->H * d->W * 256 >= (1ll << 31)) return 0;
     if (d->N * (d->H / CF_TH) * (d->W / CF_TW) >= 65536) return 0;
-    const bool fwd_pro = d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT;
+    const bool fwd_pro = d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT ||
+                         (d->pro_mode == SISR_PRO_RES_AFFINE && d->x2 && d->x_out && d->pa && d->pd);
     if (fwd_pro && !d->res && !d->bnb_part) return 1;
     const bool bwd_pro = d->pro_mode == SISR_PRO_BNBWD || d->pro_mode == SISR_PRO_BNACT_BWD;
     if (bwd_pro && !d->stat_part && !d->bias && (!d->bnb_part || (d->bnb_x && !d->bnbx_bf16))) return 2;
@@ -451,7 +462,7 @@ static int launch_cf(const CTrunkF32Args& a, hipStream_t st) {
 int sisr_conv2d_trunk_f32_launch(const SisrConvDesc* d, hipStream_t st) {
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
     CTrunkF32Args a;
-    a.x1 = d->x1; a.x2 = d->x2; a.pa = d->pa; a.pb = d->pb; a.pd = d->pd; a.ps = d->ps; a.pt = d->pt;
+    a.x1 = d->x1; a.x2 = d->x2; a.x_out = d->x_out; a.pa = d->pa; a.pb = d->pb; a.pd = d->pd; a.ps = d->ps; a.pt = d->pt;
     a.slope_p = d->pro_slope_p; a.slope = d->pro_slope;
     a.wpk = d->wpk; a.bias = d->bias; a.res = d->res; a.y = d->y; a.stat_part = d->stat_part; a.cnt_part = d->cnt_part;
     a.N = d->N; a.H = d->H; a.W = d->W;
@@ -466,6 +477,7 @@ int sisr_conv2d_trunk_f32_launch(const SisrConvDesc* d, hipStream_t st) {
         case SISR_PRO_AFFINE_ACT: return launch_cf<SISR_PRO_AFFINE_ACT>(a, st);
         case SISR_PRO_BNBWD: return launch_cf<SISR_PRO_BNBWD>(a, st);
         case SISR_PRO_BNACT_BWD: return launch_cf<SISR_PRO_BNACT_BWD>(a, st);
+        case SISR_PRO_RES_AFFINE: return launch_cf<SISR_PRO_RES_AFFINE>(a, st);
     }
     return SISR_E_UNSUPPORTED;
 }

@@ -153,7 +153,7 @@ __device__ __forceinline__ float operand_apply(const OperandView& o, float a, fl
 
 __host__ __device__ __forceinline__ bool operand_needs_x2(int pro) {
     return pro == SISR_PRO_BNBWD || pro == SISR_PRO_BNACT_BWD || pro == SISR_PRO_ACT_BWD ||
-           pro == SISR_PRO_TANH_BWD;
+           pro == SISR_PRO_TANH_BWD || pro == SISR_PRO_RES_AFFINE;
 }
 
 // ---- lean float4 staging: prologue fixed at compile time, the thread's 4 channels are the same for

@@ -57,12 +57,13 @@ def _align4(n):
 
 class Operand:
     """x1 (and x2) + prologue: see SISR_PRO_* in include/sisr_hip.h.  dims = logical (N,H,W,C)."""
-    __slots__ = ('x1', 'x2', 'pa', 'pb', 'pd', 'ps', 'pt', 'mode', 'pro', 'slope', 'dims')
+    __slots__ = ('x1', 'x2', 'pa', 'pb', 'pd', 'ps', 'pt', 'mode', 'pro', 'slope', 'dims', 'x_out')
 
     def __init__(self, x1, dims, pro=L.PRO_NONE, mode=L.X_NHWC, x2=None, pa=None, pb=None, pd=None,
                  ps=None, pt=None, slope=None):
         self.x1, self.x2, self.pa, self.pb, self.pd, self.ps, self.pt = x1, x2, pa, pb, pd, ps, pt
         self.mode, self.pro, self.slope, self.dims = mode, pro, slope, dims
+        self.x_out = None
 
     @staticmethod
     def plain(t, dims=None, mode=L.X_NHWC):
@@ -77,6 +78,15 @@ class Operand:
     def affine_act(t, scale, shift, slope=1.0):
         return Operand(t, tuple(t.shape), pro=L.PRO_AFFINE_ACT, pa=scale, pd=shift, slope=slope)
 
+    @staticmethod
+    def res_affine(res, res_slope, t, scale, shift, out):
+        """lrelu(res, res_slope) + (scale*t + shift) -- a residual block's skip sum x + BN2(c2) (model_generator.py:19)
+        formed in the consuming conv's staging; the conv also stores the sum to `out` (persistent trunk kernels only:
+        ask trunk_takes_skip_sum() first)."""
+        op = Operand(res, tuple(res.shape), pro=L.PRO_RES_AFFINE, x2=t, pa=scale, pd=shift, slope=res_slope)
+        op.x_out = out
+        return op
+
     def fill(self, d, g=False):
         """write this operand into a ConvDesc / WgradDesc (g=True: the output-gradient operand)"""
         names = (('g1', 'g2', 'qa', 'qb', 'qd', 'qs', 'qt', 'g_mode', 'gpro_mode', 'gpro_slope_p', 'gpro_slope')
@@ -89,6 +99,8 @@ class Operand:
         setattr(d, 'g_bf16' if g else 'x_bf16', _bf(self.x1))
         setattr(d, names[7], self.mode)
         setattr(d, names[8], self.pro)
+        if not g and hasattr(d, 'x_out'):
+            d.x_out = _ptr(self.x_out)
         if isinstance(self.slope, torch.Tensor):
             setattr(d, names[9], self.slope.data_ptr())
             setattr(d, names[10], 1.0)
@@ -375,6 +387,21 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
     else:
         L.check(lib.sisr_conv2d_f32(C.byref(f), _stream()), 'sisr_conv2d_f32(fwd)')
     return out, sp, cp
+
+
+def trunk_takes_skip_sum(prep, res, t):
+    """the forward conv of `prep` runs on a persistent trunk kernel that can form the skip sum lrelu(res) + BN(t) in its
+    staging (Operand.res_affine); SISR_FUSE_SKIP=0 keeps the separate elementwise pass"""
+    if os.environ.get('SISR_FUSE_SKIP', '1') == '0' or res.dtype != t.dtype or tuple(res.shape) != tuple(t.shape):
+        return False
+    f = _copy_struct(prep.plans[0])
+    if (f.N, f.H, f.W, f.Cin) != tuple(res.shape):
+        return False
+    lib = L.lib()
+    f.x1 = f.x2 = f.x_out = f.pa = f.pd = f.wpk = f.y = res.data_ptr()         # (non-null placeholders: eligibility only)
+    f.pro_mode = L.PRO_RES_AFFINE
+    f.x_bf16 = f.y_bf16 = _bf(res)
+    return (lib.sisr_conv2d_trunk_eligible if prep.kinds[0] else lib.sisr_conv2d_trunk_f32_eligible)(C.byref(f)) == 1
 
 
 def can_fuse_bn_backward(prep):

@@ -87,20 +87,37 @@ def run_forward(topo, x, training):
     t0_pre, _, _ = E.conv_forward(P[id(topo.first)], x_op, bias=topo.first.bias)
     sv.t0_pre = t0_pre
     cur_raw, cur_slope = t0_pre, topo.first_prelu       # current activation = lrelu(cur_raw, cur_slope)
+    pending = None                                      # (c2, k2) of the previous block: its skip sum is still to be formed
+
+    def next_input(prep):
+        """the operand of the next trunk conv: the previous block's output x + BN2(c2).  Where that conv runs on a
+        persistent trunk kernel the sum is formed in ITS staging (and stored once as a side effect) instead of in an
+        elementwise pass of its own; either way (cur_raw, None) names the materialised sum afterwards."""
+        nonlocal cur_raw, cur_slope, pending
+        if pending is not None:
+            c2, k2 = pending
+            pending = None
+            if E.trunk_takes_skip_sum(prep, cur_raw, c2):
+                out = torch.empty_like(cur_raw)
+                op = Operand.res_affine(cur_raw, cur_slope, c2, k2[0], k2[1], out)
+                cur_raw, cur_slope = out, None
+                return op
+            cur_raw, cur_slope = E.eltwise_res_affine(cur_raw, cur_slope, c2, k2[0], k2[1]), None
+        return Operand.act(cur_raw, cur_slope) if cur_slope is not None else Operand.plain(cur_raw)
+
     for b in topo.blocks:
         rec = Saved()
-        rec.in_raw, rec.in_slope = cur_raw, cur_slope
-        in_op = Operand.act(cur_raw, cur_slope) if cur_slope is not None else Operand.plain(cur_raw)
+        in_op = next_input(P[id(b['c1'])])
+        rec.in_raw, rec.in_slope = cur_raw, cur_slope   # (the materialised input: written by this conv when fused)
         o1 = E.conv_forward(P[id(b['c1'])], in_op, bias=b['c1'].bias, stats=training)
         rec.c1, rec.k1 = o1[0], bn_consts(o1, b['bn1'])
         o2 = E.conv_forward(P[id(b['c2'])], Operand.affine_act(rec.c1, rec.k1[0], rec.k1[1], b['prelu']),
                             bias=b['c2'].bias, stats=training)
         rec.c2, rec.k2 = o2[0], bn_consts(o2, b['bn2'])
-        cur_raw = E.eltwise_res_affine(cur_raw, cur_slope, rec.c2, rec.k2[0], rec.k2[1])
-        cur_slope = None
+        pending = (rec.c2, rec.k2)
         sv.blocks.append(rec)
+    in_op = next_input(P[id(topo.trunk_end)])
     sv.xl_raw, sv.xl_slope = cur_raw, cur_slope
-    in_op = Operand.act(cur_raw, cur_slope) if cur_slope is not None else Operand.plain(cur_raw)
     oe = E.conv_forward(P[id(topo.trunk_end)], in_op, bias=topo.trunk_end.bias, stats=training)
     sv.ce, sv.ke = oe[0], bn_consts(oe, topo.trunk_bn)
     if topo.long_skip:

@@ -146,3 +146,32 @@ def test_forward_no_end_matches_oracle():
     ref = {k: st[k].grad for k in got}
     assert grads_close(got, ref, TOL) == []
     assert all(p.grad is None for k, p in net.named_parameters() if k.startswith('base.end'))
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_fused_skip_sums_reproduce_the_unfused_schedule(precision, monkeypatch):
+    """Generator forward + backward with the residual blocks' skip sums formed inside the next conv's staging
+    (SISR_PRO_RES_AFFINE, the default on trunk-eligible sizes) against the schedule with the separate elementwise pass
+    (SISR_FUSE_SKIP=0): the staged values are the same expression, so output and every gradient must be bit-identical"""
+    E, mg = pkg('engine'), pkg('model_generator')
+    E.set_precision(precision)
+    try:
+        torch.manual_seed(0)
+        net = mg.Generator(4, 64, 256, [2], use_sn=True).cuda().train()
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        g = torch.Generator().manual_seed(5)
+        x = (torch.rand(2, 3, 16, 32, generator=g) * 2 - 1).cuda()
+        r = (torch.rand(2, 3, 32, 64, generator=g) * 2 - 1).cuda()
+        res = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_FUSE_SKIP', sw)
+            net.load_state_dict(state)
+            net.zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            out = net(xin)
+            (out * r).sum().backward()
+            res[sw] = (out.detach().clone(), xin.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()})
+        assert torch.equal(res['1'][0], res['0'][0]) and torch.equal(res['1'][1], res['0'][1])
+        assert all(torch.equal(res['1'][2][k], res['0'][2][k]) for k in res['1'][2])
+    finally:
+        E.set_precision('fp32')

@@ -718,3 +718,38 @@ def test_trunk_kernel_fp32_fused_bn_backward_reductions(E, L, shape, pro, res, a
             assert maxrel(a_, b_) < 2e-5
     monkeypatch.setenv('SISR_TRUNK_F32CONV', '0')                        # generic kernel: no fusion, no rows
     assert not E.can_fuse_bn_backward(p)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('res_slope', [None, 0.25])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (1, 96, 96)])
+def test_trunk_kernels_form_the_skip_sum_in_their_staging(E, L, shape, res_slope, precision, monkeypatch):
+    """SISR_PRO_RES_AFFINE (both persistent forward kernels): conv(lrelu(res) + (scale * t + shift)) with the sum stored
+    once as a side effect -- against the separate elementwise pass followed by the plain conv: the materialised sum must be
+    bit-identical (same fp32 expression, same rounding), the conv output equal up to summation order, statistics equal"""
+    n, h, w = shape
+    if precision == 'bf16':
+        monkeypatch.setenv('SISR_STORAGE', 'bf16')
+    E.set_precision(precision)
+    try:
+        dt = E.act_dtype(64)
+        resid = nhwc(_rand((n, 64, h, w), 171) * 2.0).cuda().to(dt)
+        t = nhwc(_rand((n, 64, h, w), 172) * 2.0).cuda().to(dt)
+        sc, sh = (_rand((64,), 173) * 0.5 + 1.0).cuda(), (_rand((64,), 174) * 0.3).cuda()
+        wt = _rand((64, 64, 3, 3), 175, (1.0 / 576) ** 0.5 * 1.7)
+        b = _rand((64,), 176, 0.1)
+        slope = None if res_slope is None else torch.tensor([res_slope], device='cuda')
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 64, 3, 1, 1))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        assert E.trunk_takes_skip_sum(p, resid, t)
+        out = torch.empty_like(resid)
+        y1, sp1, cp1 = E.conv_forward(p, E.Operand.res_affine(resid, slope, t, sc, sh, out), bias=ref.bias, stats=True)
+        summed = E.eltwise_res_affine(resid, slope, t, sc, sh)
+        y0, sp0, cp0 = E.conv_forward(p, E.Operand.plain(summed), bias=ref.bias, stats=True)
+        assert torch.equal(out, summed)
+        assert torch.equal(y1, y0)                                  # same kernel, same staged values
+        assert torch.equal(sp1, sp0) and torch.equal(cp1, cp0)
+        monkeypatch.setenv('SISR_FUSE_SKIP', '0')
+        assert not E.trunk_takes_skip_sum(p, resid, t)
+    finally:
+        E.set_precision('fp32')
