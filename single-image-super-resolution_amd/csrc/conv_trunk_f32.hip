@@ -36,6 +36,19 @@ typedef unsigned cf_u32x4 __attribute__((ext_vector_type(4)));
 #define CF_KROWP 100                        // packed fp32 weights: [chunk][r][cout 64][krow = s * 33 + ci], rows of 100
 #define CF_PS 33
 
+// phase timeline, developer build only (make trace; tools/trace_trunk.py with ROLE=fwd SISR_PRECISION=fp32)
+#ifdef SISR_CONV_TRACE
+__device__ unsigned long long sisr_cftrace_buf[512 * 128];
+#define CFT(k) do { if (threadIdx.x == 0 && blockIdx.x < 512 && (k) < 64) sisr_cftrace_buf[blockIdx.x * 128 + (k)] = wall_clock64(); } while (0)
+#define CFTP(k) do { if (threadIdx.x == 256 && blockIdx.x < 512 && (k) < 64) sisr_cftrace_buf[blockIdx.x * 128 + 64 + (k)] = wall_clock64(); } while (0)
+extern "C" int sisr_cftrace_read(void* dst, int n_u64) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sisr_cftrace_buf), (size_t)n_u64 * 8, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define CFT(k)
+#define CFTP(k)
+#endif
+
 struct CTrunkF32Args {
     const float *x1, *x2;
     float* x_out;                         // skip-sum prologue: the materialised operand
@@ -82,8 +95,11 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
         tx = rem - ty * a.tiles_x;
     };
 
-    // ---- this workgroup's weights into LDS: global rows are contiguous over (s, ci) for one cout, LDS rows over couts ---
-    {
+    CFT(0);
+    // ---- this workgroup's weights into LDS: global rows are contiguous over (s, ci) for one cout, LDS rows over couts.
+    // Every wave takes part, from inside its role branch: the producers put the loads of their first two stages in flight
+    // before it ---
+    auto fill_weights = [&]() {
         float* wl = reinterpret_cast<float*>(lds);
         constexpr int W_IT = 2 * 9 * 32 * 32 / CF_THREADS;                     // 36 elements per thread
         float wv[W_IT];
@@ -102,8 +118,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             const int q = qr / 3, r = qr - 3 * q;
             wl[((q * 9 + r * 3 + s) * 32 + ci) * CF_WROW + co] = wv[it];
         }
-    }
-    __syncthreads();
+    };
 
     const int n_mine = stream < a.total ? (a.total - stream + a.streams - 1) / a.streams : 0;   // pixel tiles of this workgroup
     const int n_stages = 2 * n_mine;                                                               // (tile, channel half)
@@ -200,18 +215,28 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
 
         issue(0, stA);
         issue(1, stB);
+        fill_weights();
+        __syncthreads();
         if (n_stages > 0) commit(0, stA);
         __syncthreads();
         // unrolled by two: each set has a fixed name in each half (stB holds stage j + 1 in the first)
         int j = 0;
         while (j < n_stages) {
+            CFTP(4 + 6 * j);
             issue(j + 2, stA);
+            CFTP(5 + 6 * j);
             if (j + 1 < n_stages) commit(j + 1, stB);
+            CFTP(8 + 6 * j);
             __syncthreads();      // stage j + 1 is complete; the consumers have finished reading stage j
+            CFTP(9 + 6 * j);
             if (++j >= n_stages) break;
+            CFTP(4 + 6 * j);
             issue(j + 2, stB);
+            CFTP(5 + 6 * j);
             if (j + 1 < n_stages) commit(j + 1, stA);
+            CFTP(8 + 6 * j);
             __syncthreads();
+            CFTP(9 + 6 * j);
             ++j;
         }
     } else {
@@ -235,9 +260,12 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             b_sc = a.bnb_scale[co]; b_sf = a.bnb_shift[co]; b_mu = a.bnb_mean[co]; b_is = a.bnb_invstd[co];
             b_slope = a.bnb_slope_p ? a.bnb_slope_p[0] : a.bnb_slope;
         }
+        fill_weights();
+        __syncthreads();
         __syncthreads();
         for (int j = 0; j < n_stages; ++j) {
             const int q = j & 1;
+            CFT(4 + 6 * j);
             int n, ty, tx;
             tile_coords(stream + (j >> 1) * a.streams, n, ty, tx);
             const unsigned obase = (unsigned)((((n * a.H + ty * CF_TH + 2 * wave) * a.W + tx * CF_TW) * 64 + co) * 4);
@@ -288,6 +316,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
                 if (u + 2 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
+            CFT(6 + 6 * j);
             if (q == 1) {
                 // ---- epilogue of the tile: skip gradient, statistics, stores (128 contiguous bytes per pixel and half wave) ---
                 if (a.res != nullptr) {
@@ -328,8 +357,11 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
                                                           obase + (unsigned)(((p >> 4) * a.W + (p & 15)) * 256), 0, 0);
                 }
             }
+            CFT(8 + 6 * j);
             __syncthreads();
+            CFT(9 + 6 * j);
         }
+        CFT(3);
 
         // ---- this workgroup's 32 channels of the statistics row it shares with its cout partner ------------------------------
         if (a.stat_part != nullptr) {
@@ -391,6 +423,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             if (tid == 0 && hc == 0) a.cnt_part[stream] = nn;
         }
     }
+    CFT(63);
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------

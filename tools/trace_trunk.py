@@ -5,12 +5,13 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import bench
 dev = torch.device('cuda', 0)
-print(bench.kernel_rooflines(dev, 'bf16', iters=3, only=(os.environ.get('ROLE', 'fwd'),))[0]['launch_ms'])
+prec = os.environ.get('SISR_PRECISION', 'bf16')
+print(bench.kernel_rooflines(dev, prec, iters=3, only=(os.environ.get('ROLE', 'fwd'),))[0]['launch_ms'])
 torch.cuda.synchronize()
 L = C.CDLL(os.environ['SISR_LIB'])
 slots = 128
 buf = np.zeros(512 * slots, dtype=np.uint64)
-reader = L.sisr_wttrace_read if os.environ.get('ROLE', 'fwd') == 'wgrad' else L.sisr_ttrace_read
+reader = L.sisr_cftrace_read if prec == 'fp32' else (L.sisr_wttrace_read if os.environ.get('ROLE', 'fwd') == 'wgrad' else L.sisr_ttrace_read)
 assert reader(buf.ctypes.data_as(C.c_void_p), C.c_int(buf.size)) == 0
 t = buf.reshape(512, slots).astype(np.int64) * 10e-3
 t = t[t[:, 0] > 0]
