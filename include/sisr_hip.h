@@ -140,8 +140,8 @@ typedef struct SisrWgradDesc {
 } SisrWgradDesc;
 
 int sisr_wgrad_plan(SisrWgradDesc *d, int32_t max_pixel_blocks);
-/* bf16 matrix-core variants (v_mfma_f32_32x32x16_bf16, fp32 accumulate; activations fp32 in HBM,
- * converted while staged into LDS).  Same descriptors; `wpk` points at the bf16 image written by
+/* bf16 matrix-core variants (v_mfma_f32_32x32x16_bf16, fp32 accumulate; activations fp32 or bf16 in HBM -- see the
+ * *_bf16 storage flags -- converted while staged into LDS).  Same descriptors; `wpk` points at the bf16 image written by
  * sisr_weights_prepare (wbf_fwd / wbf_dgrad).  Requirements: Cin % 32 == 0, KH*KW <= 9, NHWC
  * operands; SISR_E_UNSUPPORTED otherwise (callers keep the fp32 kernels for those layers). */
 int sisr_conv2d_plan_bf16(SisrConvDesc *d);

@@ -14,7 +14,8 @@ import torch
 from . import _lib as L
 
 # 'fp32': exact-fp32 MFMA everywhere (the parity build).  'bf16': layers with Cin % 32 == 0 run their
-# contraction on the bf16 matrix cores (fp32 accumulate, fp32 statistics, fp32 tensors in HBM).
+# contraction on the bf16 matrix cores (fp32 accumulate, fp32 statistics) and keep their NHWC tensors as bf16 in HBM
+# (storage_bf16() below).
 PRECISION = os.environ.get('SISR_PRECISION', 'fp32')
 
 
@@ -27,7 +28,7 @@ def set_precision(p):
 def storage_bf16():
     """bf16 build: NHWC activation / gradient tensors whose channel count is a multiple of 32 live in HBM as bf16
     (SURVEY 8d's bf16 bytes); arithmetic, accumulation and BatchNorm statistics stay fp32.  SISR_STORAGE=f32 keeps
-    fp32 tensors with bf16 matrix-core operands (round 1's layout; A/B switch)."""
+    fp32 tensors with bf16 matrix-core operands (the earlier layout; A/B switch)."""
     return PRECISION == 'bf16' and os.environ.get('SISR_STORAGE', 'bf16') != 'f32'
 
 
