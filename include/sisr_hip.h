@@ -89,6 +89,14 @@ typedef struct SisrConvDesc {
     const float *bnb_slope_p;
     float *bnb_part;
     float *x_out;                            /* SISR_PRO_RES_AFFINE: the materialised operand, layout / type of x1 */
+    /* Deferred BatchNorm finalisation (persistent forward trunk kernels, prologues AFFINE_ACT / RES_AFFINE): when
+     * fin_stat is set, pa / pd are NOT read -- every workgroup merges the fin_rows statistics rows (fin_stat [rows][2][Cin]
+     * mean / M2, fin_cnt [rows]) of the BatchNorm whose apply the prologue is, exactly as sisr_bn_finalize does (Chan's
+     * formula in double), and uses scale = gamma * invstd, shift = beta - mean * scale; workgroup 0 also writes
+     * fin_k [4][Cin] = scale, shift, mean, invstd and updates the running statistics (momentum, unbiased variance).
+     * Saves the 5-6 us sisr_bn_finalize launch between two convs. */
+    const float *fin_stat, *fin_cnt, *fin_gamma, *fin_beta;
+    float *fin_rm, *fin_rv, *fin_k;
     int32_t N, H, W, Cin;                    /* logical input                                 */
     int32_t Ho, Wo, Cout;                    /* logical output grid                           */
     int32_t KH, KW, stride, pad_y, pad_x;
@@ -104,6 +112,7 @@ typedef struct SisrConvDesc {
      * activations and gradients as bf16 in HBM; all arithmetic, accumulation and statistics stay fp32).
      * x_bf16: x1 and x2;  y_bf16: y (NHWC / NHWC_SHUFFLE2 only);  res_bf16: res;  bnbx_bf16: bnb_x. */
     int32_t x_bf16, y_bf16, res_bf16, bnbx_bf16;
+    int32_t fin_rows; float fin_momentum, fin_eps; int32_t fin_pad_;
     SisrConvPlan plan;
 } SisrConvDesc;
 

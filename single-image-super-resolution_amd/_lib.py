@@ -33,13 +33,15 @@ class ConvPlan(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = ([(n, _f) for n in ('x1', 'x2', 'pa', 'pb', 'pd', 'ps', 'pt', 'wpk', 'bias', 'res', 'y',
                                    'stat_part', 'cnt_part', 'bnb_x', 'bnb_scale', 'bnb_shift', 'bnb_mean',
-                                   'bnb_invstd', 'bnb_slope_p', 'bnb_part', 'x_out')] +
+                                   'bnb_invstd', 'bnb_slope_p', 'bnb_part', 'x_out',
+                                   'fin_stat', 'fin_cnt', 'fin_gamma', 'fin_beta', 'fin_rm', 'fin_rv', 'fin_k')] +
                 [(n, _i32) for n in ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride',
                                      'pad_y', 'pad_x', 'x_mode', 'pro_mode')] +
                 [('pro_slope_p', _f), ('pro_slope', _f32)] +
                 [('y_mode', _i32), ('epi_act', _i32), ('bnb_act', _i32), ('bnb_slope', _f32)] +
                 [(n, _i32) for n in ('y_sy', 'y_oy', 'y_sx', 'y_ox', 'y_H', 'y_W')] +
                 [(n, _i32) for n in ('x_bf16', 'y_bf16', 'res_bf16', 'bnbx_bf16')] +
+                [('fin_rows', _i32), ('fin_momentum', _f32), ('fin_eps', _f32), ('fin_pad_', _i32)] +
                 [('plan', ConvPlan)])
 
 

@@ -67,6 +67,7 @@ extern "C" int sisr_ttrace_read(void* dst, int n_u64) {
 struct TrunkArgs {
     const void *x1, *x2;                  // input operand(s), bf16 NHWC [N][H][W][64]
     void* x_out;                          // skip-sum prologue: the materialised operand
+    BnFinArgs fin;                        // deferred BatchNorm finalisation (fin.stat != nullptr): pa / pd come from here
     const float *pa, *pb, *pd, *ps, *pt;  // per-channel prologue constants
     const float* slope_p; float slope;
     const void* wpk;                      // bf16 image [2 chunks][64 couts][9 taps][32 cin]
@@ -200,6 +201,11 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     bool easy_slope = true;
 
     TT(0);
+    // deferred BatchNorm finalisation: scale / shift of the prologue's BatchNorm from its statistics rows, in LDS (the halo
+    // buffers are free yet: 12 KB of scratch, the constants behind the reduction scratch)
+    float* kfin = red + 4 * 32 * 3;
+    const bool fin = (PRO == SISR_PRO_AFFINE_ACT || PRO == SISR_PRO_RES_AFFINE) && a.fin.stat != nullptr;
+    if (fin) bn_finalize_in_kernel(a.fin, reinterpret_cast<double*>(lds), kfin, blockIdx.x == 0);
     // (role state is set up INSIDE the role branches below: set up ahead of the split, every register of both roles
     // meets in one merge block and the allocator spills weights at load time)
     auto init_consumer = [&]() {
@@ -221,9 +227,14 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
         slope = a.slope_p ? a.slope_p[0] : a.slope;
         easy_slope = slope >= 0.f && slope <= 1.f;
         halo_map_init(hm, ptid, a.W);
+    };
+    auto init_constants = [&]() {
         if (PRO == SISR_PRO_AFFINE_ACT || TWO) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { ka[j] = a.pa[oct * 8 + j]; kd[j] = a.pd[oct * 8 + j]; }
+            for (int j = 0; j < 8; ++j) {
+                ka[j] = fin ? kfin[oct * 8 + j] : a.pa[oct * 8 + j];
+                kd[j] = fin ? kfin[64 + oct * 8 + j] : a.pd[oct * 8 + j];
+            }
         }
     };
     // two staging register sets: the loads of tile T + 2 are in flight while tile T + 1 is transformed and written to
@@ -274,6 +285,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
         // ---- producers: tile T + 1 into the other buffer while the consumers work on tile T ------------------------------
         init_producer();
         int T = blockIdx.x;
+        init_constants();
         issue(T, stA);
         issue(T + gridDim.x, stB);
         if (T < a.total) commit(lds, stA);
@@ -718,7 +730,10 @@ extern "C" int sisr_conv2d_trunk_eligible(const SisrConvDesc* d) {
     if ((int64_t)d->N * d->H * d->W * 128 >= (1ll << 31)) return 0;
     if (d->N * (d->H / TK_TH) * (d->W / TK_TW) >= 65536) return 0;
     const bool fwd_pro = d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT ||
-                         (d->pro_mode == SISR_PRO_RES_AFFINE && d->x2 && d->x_out && d->pa && d->pd);
+                         (d->pro_mode == SISR_PRO_RES_AFFINE && d->x2 && d->x_out && ((d->pa && d->pd) || d->fin_stat));
+    if (d->fin_stat && !((d->pro_mode == SISR_PRO_AFFINE_ACT || d->pro_mode == SISR_PRO_RES_AFFINE) && d->fin_cnt && d->fin_gamma &&
+                         d->fin_beta && d->fin_rm && d->fin_rv && d->fin_k && d->fin_rows > 0))
+        return 0;
     if (fwd_pro && !d->res && !d->bnb_part) return 1;           // forward role
     const bool bwd_pro = d->pro_mode == SISR_PRO_BNBWD || d->pro_mode == SISR_PRO_BNACT_BWD;
     if (bwd_pro && !d->stat_part && !d->bias && (!d->res || d->res_bf16) && (!d->bnb_part || d->bnbx_bf16)) return 2;   // data-gradient role
@@ -735,7 +750,7 @@ extern "C" int sisr_conv2d_bf16_parts(const SisrConvDesc* d) {
 
 template <int PRO>
 static int launch_trunk_fwd(const TrunkArgs& a, int grid, hipStream_t st) {
-    constexpr int lds_bytes = 2 * TK_HALO_BYTES + 4 * 32 * TK_YS * 2 + 4 * 32 * 3 * 4;
+    constexpr int lds_bytes = 2 * TK_HALO_BYTES + 4 * 32 * TK_YS * 2 + 4 * 32 * 3 * 4 + 128 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_trunk_fwd_kernel<PRO>),
@@ -766,6 +781,8 @@ static int launch_trunk_bwd(const TrunkArgs& a, int grid, bool images, hipStream
 // called by sisr_conv2d_bf16 for eligible descriptors
 int sisr_conv2d_trunk_launch(const SisrConvDesc* d, hipStream_t st) {
     TrunkArgs a;
+    a.fin.stat = d->fin_stat; a.fin.cnt = d->fin_cnt; a.fin.gamma = d->fin_gamma; a.fin.beta = d->fin_beta;
+    a.fin.rm = d->fin_rm; a.fin.rv = d->fin_rv; a.fin.k = d->fin_k; a.fin.rows = d->fin_rows; a.fin.momentum = d->fin_momentum; a.fin.eps = d->fin_eps;
     a.x1 = d->x1; a.x2 = d->x2; a.x_out = d->x_out; a.pa = d->pa; a.pb = d->pb; a.pd = d->pd; a.ps = d->ps; a.pt = d->pt;
     a.slope_p = d->pro_slope_p; a.slope = d->pro_slope;
     a.wpk = d->wpk; a.bias = d->bias; a.y = d->y; a.stat_part = d->stat_part; a.cnt_part = d->cnt_part;

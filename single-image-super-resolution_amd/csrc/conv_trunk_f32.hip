@@ -52,6 +52,7 @@ extern "C" int sisr_cftrace_read(void* dst, int n_u64) {
 struct CTrunkF32Args {
     const float *x1, *x2;
     float* x_out;                         // skip-sum prologue: the materialised operand
+    BnFinArgs fin;                        // deferred BatchNorm finalisation (fin.stat != nullptr): pa / pd come from here
     const float *pa, *pb, *pd, *ps, *pt;
     const float* slope_p; float slope;
     const float* wpk;
@@ -96,6 +97,11 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
     };
 
     CFT(0);
+    // deferred BatchNorm finalisation: scale / shift of the prologue's BatchNorm from its statistics rows, in LDS (the halo
+    // buffers are free yet: 12 KB of scratch; the constants behind the reduction scratch)
+    float* kfin = red + 4 * 32 * 3;
+    const bool fin = (PRO == SISR_PRO_AFFINE_ACT || PRO == SISR_PRO_RES_AFFINE) && a.fin.stat != nullptr;
+    if (fin) bn_finalize_in_kernel(a.fin, reinterpret_cast<double*>(halo0), kfin, blockIdx.x == 0);
     // ---- this workgroup's weights into LDS: global rows are contiguous over (s, ci) for one cout, LDS rows over couts.
     // Every wave takes part, from inside its role branch: the producers put the loads of their first two stages in flight
     // before it ---
@@ -130,17 +136,6 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
         const int tiles_y = a.per_img / a.tiles_x;
         const float slope = PRO != SISR_PRO_NONE ? (a.slope_p ? a.slope_p[0] : a.slope) : 1.f;
         f32x4 ka[2], kb[2], kd[2], ks[2], kt[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = q * 32 + quad * 4 + j;
-                ka[q][j] = (PRO == SISR_PRO_AFFINE_ACT || TWO) ? a.pa[c] : 1.f;
-                kd[q][j] = (PRO == SISR_PRO_AFFINE_ACT || TWO) ? a.pd[c] : 0.f;
-                kb[q][j] = (TWO && !SUM) ? a.pb[c] : 0.f;
-                ks[q][j] = PRO == SISR_PRO_BNACT_BWD ? a.ps[c] : 0.f;
-                kt[q][j] = PRO == SISR_PRO_BNACT_BWD ? a.pt[c] : 0.f;
-            }
         int rel[CF_ITEMS];
         unsigned flags = 0;                         // 4 bits per item: halo row 0 / last row / column 0 / last column; 15 = beyond
 #pragma unroll
@@ -215,6 +210,17 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
 
         issue(0, stA);
         issue(1, stB);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = q * 32 + quad * 4 + j;
+                ka[q][j] = fin ? kfin[c] : (PRO == SISR_PRO_AFFINE_ACT || TWO) ? a.pa[c] : 1.f;
+                kd[q][j] = fin ? kfin[64 + c] : (PRO == SISR_PRO_AFFINE_ACT || TWO) ? a.pd[c] : 0.f;
+                kb[q][j] = (TWO && !SUM) ? a.pb[c] : 0.f;
+                ks[q][j] = PRO == SISR_PRO_BNACT_BWD ? a.ps[c] : 0.f;
+                kt[q][j] = PRO == SISR_PRO_BNACT_BWD ? a.pt[c] : 0.f;
+            }
         fill_weights();
         __syncthreads();
         if (n_stages > 0) commit(0, stA);
@@ -457,7 +463,10 @@ extern "C" int sisr_conv2d_trunk_f32_eligible(const SisrConvDesc* d) {
     if ((int64_t)d->N * d->H * d->W * 256 >= (1ll << 31)) return 0;
     if (d->N * (d->H / CF_TH) * (d->W / CF_TW) >= 65536) return 0;
     const bool fwd_pro = d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT ||
-                         (d->pro_mode == SISR_PRO_RES_AFFINE && d->x2 && d->x_out && d->pa && d->pd);
+                         (d->pro_mode == SISR_PRO_RES_AFFINE && d->x2 && d->x_out && ((d->pa && d->pd) || d->fin_stat));
+    if (d->fin_stat && !((d->pro_mode == SISR_PRO_AFFINE_ACT || d->pro_mode == SISR_PRO_RES_AFFINE) && d->fin_cnt && d->fin_gamma &&
+                         d->fin_beta && d->fin_rm && d->fin_rv && d->fin_k && d->fin_rows > 0))
+        return 0;
     if (fwd_pro && !d->res && !d->bnb_part) return 1;
     const bool bwd_pro = d->pro_mode == SISR_PRO_BNBWD || d->pro_mode == SISR_PRO_BNACT_BWD;
     if (bwd_pro && !d->stat_part && !d->bias && (!d->bnb_part || (d->bnb_x && !d->bnbx_bf16))) return 2;
@@ -478,7 +487,7 @@ extern "C" int sisr_conv2d_f32_bnb_parts(const SisrConvDesc* d) {
 
 template <int PRO>
 static int launch_cf(const CTrunkF32Args& a, hipStream_t st) {
-    constexpr int lds_bytes = 2 * CF_WCHUNK_BYTES + 2 * CF_HALO_BYTES + 4 * 32 * 3 * 4;
+    constexpr int lds_bytes = 2 * CF_WCHUNK_BYTES + 2 * CF_HALO_BYTES + 4 * 32 * 3 * 4 + 128 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_trunk_f32_kernel<PRO>),
@@ -495,6 +504,8 @@ static int launch_cf(const CTrunkF32Args& a, hipStream_t st) {
 int sisr_conv2d_trunk_f32_launch(const SisrConvDesc* d, hipStream_t st) {
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
     CTrunkF32Args a;
+    a.fin.stat = d->fin_stat; a.fin.cnt = d->fin_cnt; a.fin.gamma = d->fin_gamma; a.fin.beta = d->fin_beta;
+    a.fin.rm = d->fin_rm; a.fin.rv = d->fin_rv; a.fin.k = d->fin_k; a.fin.rows = d->fin_rows; a.fin.momentum = d->fin_momentum; a.fin.eps = d->fin_eps;
     a.x1 = d->x1; a.x2 = d->x2; a.x_out = d->x_out; a.pa = d->pa; a.pb = d->pb; a.pd = d->pd; a.ps = d->ps; a.pt = d->pt;
     a.slope_p = d->pro_slope_p; a.slope = d->pro_slope;
     a.wpk = d->wpk; a.bias = d->bias; a.res = d->res; a.y = d->y; a.stat_part = d->stat_part; a.cnt_part = d->cnt_part;

@@ -314,3 +314,56 @@ __device__ __forceinline__ void stage_operand_tile(const OperandView& o, float* 
     }
     if (tid < slack) lds[npix * PS + tid] = 0.f;   // slack read by zero-weight / masked K tails
 }
+
+// ---- deferred BatchNorm finalisation inside a consuming kernel (SisrConvDesc.fin_*) ---------------------------------------
+// 512 threads, 64 channels.  Every workgroup merges the statistics rows ([rows][2][64] mean / M2, [rows] counts) of the
+// BatchNorm whose apply its prologue is: shifted sums in double (shift = the first row's mean: N = sum n_b,
+// S = sum n_b (mean_b - K), Q = sum M2_b + n_b (mean_b - K)^2; mean = K + S / N, M2 = Q - S^2 / N), thread = (channel,
+// one of 8 row splits), splits combined through LDS in a fixed order.  Leaves scale / shift in kfin[0..63] / [64..127]
+// (LDS); the `writer` workgroup also stores scale, shift, mean, invstd to k [4][64] and updates the running statistics as
+// sisr_bn_finalize does (norm.hip: momentum, unbiased variance).  scratch: LDS, 8 * 64 * 3 doubles.  Two barriers.
+struct BnFinArgs {
+    const float *stat, *cnt, *gamma, *beta;
+    float *rm, *rv, *k;
+    int rows;
+    float momentum, eps;
+};
+__device__ __forceinline__ void bn_finalize_in_kernel(const BnFinArgs& f, double* scratch, float* kfin, bool writer) {
+    const int c = threadIdx.x & 63, split = threadIdx.x >> 6;
+    const double K = (double)f.stat[c];
+    double N = 0.0, S = 0.0, Q = 0.0;
+#pragma unroll 4
+    for (int t = split; t < f.rows; t += 8) {
+        const double nb = (double)f.cnt[t];
+        const double dm = (double)f.stat[(int64_t)t * 128 + c] - K;
+        N += nb;
+        S += nb * dm;
+        Q += (double)f.stat[(int64_t)t * 128 + 64 + c] + nb * dm * dm;
+    }
+    double* my = scratch + (split * 64 + c) * 3;
+    my[0] = N; my[1] = S; my[2] = Q;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        N = 0.0; S = 0.0; Q = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double* r = scratch + (j * 64 + c) * 3;
+            N += r[0]; S += r[1]; Q += r[2];
+        }
+        const double mean = K + S / N;
+        const double m2 = Q - S * S / N;
+        const double var = m2 / N;                                     // biased (normalisation)
+        const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+        const float sc = f.gamma[c] * invstd;
+        const float sh = f.beta[c] - (float)mean * sc;
+        kfin[c] = sc;
+        kfin[64 + c] = sh;
+        if (writer) {
+            f.k[c] = sc; f.k[64 + c] = sh; f.k[128 + c] = (float)mean; f.k[192 + c] = invstd;
+            const double unb = N > 1.0 ? m2 / (N - 1.0) : var;         // unbiased (running estimate)
+            f.rm[c] = (1.f - f.momentum) * f.rm[c] + f.momentum * (float)mean;
+            f.rv[c] = (1.f - f.momentum) * f.rv[c] + f.momentum * (float)unb;
+        }
+    }
+    __syncthreads();
+}

@@ -58,13 +58,14 @@ def _align4(n):
 
 class Operand:
     """x1 (and x2) + prologue: see SISR_PRO_* in include/sisr_hip.h.  dims = logical (N,H,W,C)."""
-    __slots__ = ('x1', 'x2', 'pa', 'pb', 'pd', 'ps', 'pt', 'mode', 'pro', 'slope', 'dims', 'x_out')
+    __slots__ = ('x1', 'x2', 'pa', 'pb', 'pd', 'ps', 'pt', 'mode', 'pro', 'slope', 'dims', 'x_out', 'fin')
 
     def __init__(self, x1, dims, pro=L.PRO_NONE, mode=L.X_NHWC, x2=None, pa=None, pb=None, pd=None,
                  ps=None, pt=None, slope=None):
         self.x1, self.x2, self.pa, self.pb, self.pd, self.ps, self.pt = x1, x2, pa, pb, pd, ps, pt
         self.mode, self.pro, self.slope, self.dims = mode, pro, slope, dims
         self.x_out = None
+        self.fin = None                     # LazyBN whose scale / shift are this operand's pa / pd (deferred finalisation)
 
     @staticmethod
     def plain(t, dims=None, mode=L.X_NHWC):
@@ -376,6 +377,16 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
     f.wpk, f.bias, f.res, f.y = prep.wpk_fwd.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr()
     f.y_bf16, f.res_bf16 = _bf(out), _bf(res)
     f.epi_act = epi
+    fin = op.fin
+    if fin is not None and not fin.done:
+        # deferred BatchNorm finalisation: by this conv when it runs on a persistent trunk kernel, else stand-alone first
+        fin.fill(f)
+        if os.environ.get('SISR_FUSE_BNFIN', '1') != '0' and \
+                (lib.sisr_conv2d_trunk_eligible if prep.kinds[0] else lib.sisr_conv2d_trunk_f32_eligible)(C.byref(f)) == 1:
+            fin.done = True
+        else:
+            f.fin_stat = None
+            fin.ensure()
     sp = cp = None
     if stats:
         # rows of the statistics partials: one per tile, or one per workgroup on the persistent trunk kernel
@@ -556,6 +567,39 @@ class WeightGradBatch:
                 'sisr_weights_grad')
         self._keep = (tab, work)
         return res
+
+
+class LazyBN:
+    """BatchNorm constants [4, C] (scale, shift, batch mean, invstd) that are not computed yet: the statistics rows of
+    the producing conv plus the module.  Where the conv that APPLIES this BatchNorm in its prologue runs on a persistent
+    trunk kernel, that kernel finalises the statistics itself (SisrConvDesc.fin_*: one launch less per BatchNorm);
+    anything else calls ensure(), which runs the stand-alone sisr_bn_finalize.  Either way `k` is valid in stream
+    order after the consumer (or ensure()) has been launched."""
+    __slots__ = ('sp', 'cp', 'bn', 'eps', 'momentum', 'k', 'done')
+
+    def __init__(self, sp, cp, bn, eps=1e-5, momentum=0.1):
+        self.sp, self.cp, self.bn, self.eps, self.momentum = sp, cp, bn, eps, momentum
+        self.k = torch.empty((4, bn.weight.numel()), dtype=torch.float32, device=sp.device)
+        self.done = False
+
+    def ensure(self):
+        if not self.done:
+            lib = L.lib()
+            bn, k = self.bn, self.k
+            L.check(lib.sisr_bn_finalize(self.sp.data_ptr(), self.cp.data_ptr(), self.sp.shape[0], k.shape[1],
+                                         bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                         bn.running_var.data_ptr(), self.momentum, self.eps, k[0].data_ptr(),
+                                         k[1].data_ptr(), k[2].data_ptr(), k[3].data_ptr(), _stream()), 'sisr_bn_finalize')
+            self.done = True
+        return self.k
+
+    def fill(self, d):
+        """hand the finalisation to the conv of descriptor d"""
+        bn = self.bn
+        d.fin_stat, d.fin_cnt, d.fin_rows = self.sp.data_ptr(), self.cp.data_ptr(), self.sp.shape[0]
+        d.fin_gamma, d.fin_beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+        d.fin_rm, d.fin_rv, d.fin_k = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.k.data_ptr()
+        d.fin_momentum, d.fin_eps = self.momentum, self.eps
 
 
 def bn_finalize(sp, cp, bn, eps=1e-5, momentum=0.1):

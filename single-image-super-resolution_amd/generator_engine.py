@@ -79,15 +79,19 @@ def run_forward(topo, x, training):
     sv.blocks = []
 
     def bn_consts(conv_out, bn):
+        """-> (k [4, C], LazyBN | None): in training mode the constants are finalised by whoever applies them first"""
         y, sp, cp = conv_out
-        return E.bn_finalize(sp, cp, bn) if training else E.bn_eval_consts(bn)
+        if not training:
+            return E.bn_eval_consts(bn), None
+        lz = E.LazyBN(sp, cp, bn)
+        return lz.k, lz
 
     # first conv (+ lazily applied PReLU)
     x_op = Operand.plain(x, dims=(n, h, w, cimg), mode=L.X_NCHW)
     t0_pre, _, _ = E.conv_forward(P[id(topo.first)], x_op, bias=topo.first.bias)
     sv.t0_pre = t0_pre
     cur_raw, cur_slope = t0_pre, topo.first_prelu       # current activation = lrelu(cur_raw, cur_slope)
-    pending = None                                      # (c2, k2) of the previous block: its skip sum is still to be formed
+    pending = None                                      # (c2, k2, LazyBN) of the previous block: its skip sum is still to be formed
 
     def next_input(prep):
         """the operand of the next trunk conv: the previous block's output x + BN2(c2).  Where that conv runs on a
@@ -95,13 +99,16 @@ def run_forward(topo, x, training):
         elementwise pass of its own; either way (cur_raw, None) names the materialised sum afterwards."""
         nonlocal cur_raw, cur_slope, pending
         if pending is not None:
-            c2, k2 = pending
+            c2, k2, lz = pending
             pending = None
             if E.trunk_takes_skip_sum(prep, cur_raw, c2):
                 out = torch.empty_like(cur_raw)
                 op = Operand.res_affine(cur_raw, cur_slope, c2, k2[0], k2[1], out)
+                op.fin = lz
                 cur_raw, cur_slope = out, None
                 return op
+            if lz is not None:
+                lz.ensure()
             cur_raw, cur_slope = E.eltwise_res_affine(cur_raw, cur_slope, c2, k2[0], k2[1]), None
         return Operand.act(cur_raw, cur_slope) if cur_slope is not None else Operand.plain(cur_raw)
 
@@ -110,16 +117,22 @@ def run_forward(topo, x, training):
         in_op = next_input(P[id(b['c1'])])
         rec.in_raw, rec.in_slope = cur_raw, cur_slope   # (the materialised input: written by this conv when fused)
         o1 = E.conv_forward(P[id(b['c1'])], in_op, bias=b['c1'].bias, stats=training)
-        rec.c1, rec.k1 = o1[0], bn_consts(o1, b['bn1'])
-        o2 = E.conv_forward(P[id(b['c2'])], Operand.affine_act(rec.c1, rec.k1[0], rec.k1[1], b['prelu']),
-                            bias=b['c2'].bias, stats=training)
-        rec.c2, rec.k2 = o2[0], bn_consts(o2, b['bn2'])
-        pending = (rec.c2, rec.k2)
+        rec.c1 = o1[0]
+        rec.k1, lz1 = bn_consts(o1, b['bn1'])
+        a1_op = Operand.affine_act(rec.c1, rec.k1[0], rec.k1[1], b['prelu'])
+        a1_op.fin = lz1                                 # bn1 is finalised by conv2's kernel where it can
+        o2 = E.conv_forward(P[id(b['c2'])], a1_op, bias=b['c2'].bias, stats=training)
+        rec.c2 = o2[0]
+        rec.k2, lz2 = bn_consts(o2, b['bn2'])
+        pending = (rec.c2, rec.k2, lz2)                 # ... and bn2 by the conv that forms the skip sum
         sv.blocks.append(rec)
     in_op = next_input(P[id(topo.trunk_end)])
     sv.xl_raw, sv.xl_slope = cur_raw, cur_slope
     oe = E.conv_forward(P[id(topo.trunk_end)], in_op, bias=topo.trunk_end.bias, stats=training)
-    sv.ce, sv.ke = oe[0], bn_consts(oe, topo.trunk_bn)
+    sv.ce = oe[0]
+    sv.ke, lze = bn_consts(oe, topo.trunk_bn)
+    if lze is not None:
+        lze.ensure()                                    # its consumers are the long-skip sum / the upscale conv: generic kernels
     if topo.long_skip:
         sv.t = E.eltwise_res_affine(t0_pre, topo.first_prelu, sv.ce, sv.ke[0], sv.ke[1])
         cur = Operand.plain(sv.t)

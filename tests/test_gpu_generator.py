@@ -175,3 +175,39 @@ def test_fused_skip_sums_reproduce_the_unfused_schedule(precision, monkeypatch):
         assert all(torch.equal(res['1'][2][k], res['0'][2][k]) for k in res['1'][2])
     finally:
         E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_batchnorm_finalised_inside_the_consuming_conv(precision, monkeypatch):
+    """Training-mode generator forward + backward with the BatchNorm constants finalised by the conv that applies them
+    (SisrConvDesc.fin_*, the default on trunk-eligible sizes) against the stand-alone sisr_bn_finalize launches
+    (SISR_FUSE_BNFIN=0): same statistics rows, two double-precision reductions of them -- outputs, gradients, saved
+    constants and the updated running statistics agree to fp32 rounding (bf16 build: to a few stored roundings)"""
+    E, mg = pkg('engine'), pkg('model_generator')
+    E.set_precision(precision)
+    try:
+        torch.manual_seed(0)
+        net = mg.Generator(4, 64, 256, [2], use_sn=True).cuda().train()
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        g = torch.Generator().manual_seed(5)
+        x = (torch.rand(2, 3, 16, 32, generator=g) * 2 - 1).cuda()
+        r = (torch.rand(2, 3, 32, 64, generator=g) * 2 - 1).cuda()
+        res = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_FUSE_BNFIN', sw)
+            net.load_state_dict(state)
+            net.zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            out = net(xin)
+            (out * r).sum().backward()
+            res[sw] = (out.detach().clone(), xin.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()},
+                       {k: v.clone() for k, v in net.state_dict().items() if 'running' in k})
+        tol = 1e-5 if precision == 'fp32' else 2e-2
+        assert rel_err(res['1'][0], res['0'][0]) < tol and rel_err(res['1'][1], res['0'][1]) < 10 * tol
+        for k in res['1'][2]:
+            assert rel_err(res['1'][2][k], res['0'][2][k]) < 10 * tol, k
+        for k in res['1'][3]:                          # running statistics: the same update from the same rows
+            assert rel_err(res['1'][3][k], res['0'][3][k]) < 1e-6, k
+            assert not torch.equal(res['1'][3][k], state[k]), k
+    finally:
+        E.set_precision('fp32')
