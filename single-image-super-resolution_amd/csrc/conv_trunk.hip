@@ -471,7 +471,9 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
     bf16x8 bw[9][4];
     int a_base[2] = {0, 0};
     float b_sc = 0.f, b_sf = 0.f, b_mu = 0.f, b_is = 0.f, b_slope = 1.f;
-    float rs1 = 0.f, rs2 = 0.f, rsl = 0.f;            // running sums of this lane's channel: g, g*xhat, slope term
+    // running sums of this lane's channel (two partial sums each, added at the end): g, g * xhat, slope term
+    f32x2 rs1v = {0.f, 0.f}, rs2v = {0.f, 0.f}, rslv = {0.f, 0.f};
+    f32x2 sc2 = {0.f, 0.f}, sf2 = {0.f, 0.f}, is2 = {0.f, 0.f}, nm2 = {0.f, 0.f}, sl2 = {1.f, 1.f};
     // ---- producer state ---------------------------------------------------------------------------------------------
     const int ptid = tid & 255, oct = tid & 7;
     float slope = 1.f;
@@ -493,6 +495,8 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
         if (has_x) {
             b_sc = a.bnb_scale[co]; b_sf = a.bnb_shift[co]; b_mu = a.bnb_mean[co]; b_is = a.bnb_invstd[co];
             b_slope = a.bnb_slope_p ? a.bnb_slope_p[0] : a.bnb_slope;
+            sc2 = f32x2{b_sc, b_sc}; sf2 = f32x2{b_sf, b_sf}; is2 = f32x2{b_is, b_is}; sl2 = f32x2{b_slope, b_slope};
+            nm2 = f32x2{-b_mu * b_is, -b_mu * b_is};                   // xhat = x * invstd - mean * invstd
         }
     };
     // two staging register sets: the loads of tile T + 2 are in flight while tile T + 1 is transformed and written to LDS
@@ -588,10 +592,13 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
             T += gridDim.x; cur ^= 1;
         }
     } else {
+        TT(0);
         init_consumer();
+        TT(2);
         __syncthreads();
-        int cur = 0;
-        for (int T = blockIdx.x; T < a.total; T += gridDim.x, cur ^= 1) {
+        int cur = 0, it = 0;
+        for (int T = blockIdx.x; T < a.total; T += gridDim.x, cur ^= 1, ++it) {
+            TT(4 + 6 * it);
             {
             f32x16 acc[2];
 #pragma unroll
@@ -620,40 +627,66 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
                 if (st + TK_PF < 36) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
+            TT(6 + 6 * it);
             // ---- epilogue: residual, BatchNorm-backward reductions, bf16, transposed store -------------------------------
             const __amdgpu_buffer_rsrc_t ry = bf_rsrc(a.y, xbytes);
             int n, ty, tx;
             tile_coords(T, n, ty, tx);
-            if (has_r || has_x) {
+            // residual add and BatchNorm-backward reductions, specialised at compile time on what the launch asked for (with
+            // the three flags tested per register group the epilogue was a chain of 40 short branches: 2.1 us per tile)
+            auto res_bnb = [&](auto R_, auto X_, auto A_) {
+                constexpr bool R = decltype(R_)::value, X = decltype(X_)::value, A = decltype(A_)::value;
                 const __bf16* ir = reinterpret_cast<const __bf16*>(img0 + cur * (2 * TK_IMG));
                 const __bf16* ix_ = ir + TK_IMG / 2;
+                // register group u = 4 ms + q of this lane: pixels 64g + 32ms + 8q + 4kk .. +3 (rows of the transposing read),
+                // channels 32h + 16 (l31 >> 4) ..; row tq of a read = pixel with (pixel & 3) == tq, whose octets sit at slot
+                // octet ^ 2 tq.  The reads of group u + 1 are issued before the arithmetic of group u.
+                const int oct_r = (4 * h + 2 * (grp & 1) + (tp >> 1)) ^ (2 * tq);
+                const int off0 = (64 * g + 4 * (grp >> 1) + tq) * TK_RS + 8 * oct_r + 4 * (tp & 1);
+                s16x4 pr_n = {0, 0, 0, 0}, px_n = {0, 0, 0, 0};
+                auto fetch = [&](int u) {
+                    const int off = off0 + (32 * (u >> 2) + 8 * (u & 3)) * TK_RS;
+                    if (R) pr_n = lds_tr16(ir + off);
+                    if (X) px_n = lds_tr16(ix_ + off);
+                };
+                fetch(0);
 #pragma unroll
-                for (int ms = 0; ms < 2; ++ms)
+                for (int u = 0; u < 8; ++u) {
+                    const s16x4 pr_c = pr_n, px_c = px_n;
+                    if (u + 1 < 8) fetch(u + 1);
+                    __builtin_amdgcn_sched_barrier(0);          // (keeps the compiler from hoisting all 16 reads: 32 registers it does not have)
+                    const int ms = u >> 2, q = u & 3;
+                    // packed fp32 arithmetic on the 4 values of the register group
+                    f32x4 rv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+                    if (R) rv = bf16x4_bits_to_f32(__builtin_bit_cast(u32x2, pr_c));
+                    if (X) xv = bf16x4_bits_to_f32(__builtin_bit_cast(u32x2, px_c));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        // this 16-lane group's block: pixels 64g + 32ms + 8q + 4kk .. +3 (rows), channels 32h + 16 (l31 >> 4) ..
-                        // (row tq of the read = pixel with (pixel & 3) == tq: its octets sit at slot octet ^ 2 tq)
-                        const int oct_r = (4 * h + 2 * (grp & 1) + (tp >> 1)) ^ (2 * tq);
-                        const int off = (64 * g + 32 * ms + 8 * q + 4 * (grp >> 1) + tq) * TK_RS + 8 * oct_r + 4 * (tp & 1);
-                        s16x4 pr, px4;
-                        if (has_r) pr = lds_tr16(ir + off);
-                        if (has_x) px4 = lds_tr16(ix_ + off);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float gv = acc[ms][4 * q + j];
-                            if (has_r) gv += bf16_bits_to_f32((unsigned short)pr[j]);
-                            acc[ms][4 * q + j] = gv;
-                            if (has_x) {
-                                const float xv = bf16_bits_to_f32((unsigned short)px4[j]);
-                                if (a.bnb_act) {
-                                    const float z = b_sc * xv + b_sf;
-                                    if (!(z > 0.f)) { rsl += gv * z; gv *= b_slope; }
-                                }
-                                rs1 += gv;
-                                rs2 += gv * ((xv - b_mu) * b_is);
+                    for (int jp = 0; jp < 2; ++jp) {
+                        f32x2 gv = {acc[ms][4 * q + 2 * jp], acc[ms][4 * q + 2 * jp + 1]};
+                        if (R) {
+                            gv += f32x2{rv[2 * jp], rv[2 * jp + 1]};
+                            acc[ms][4 * q + 2 * jp] = gv[0];
+                            acc[ms][4 * q + 2 * jp + 1] = gv[1];
+                        }
+                        if (X) {
+                            const f32x2 x2 = {xv[2 * jp], xv[2 * jp + 1]};
+                            if (A) {
+                                const f32x2 z = sc2 * x2 + sf2, gz = gv * z, gs = gv * sl2;
+                                const bool n0 = !(z[0] > 0.f), n1 = !(z[1] > 0.f);
+                                rslv += f32x2{n0 ? gz[0] : 0.f, n1 ? gz[1] : 0.f};
+                                gv = f32x2{n0 ? gs[0] : gv[0], n1 ? gs[1] : gv[1]};
                             }
+                            rs1v += gv;
+                            rs2v += gv * (x2 * is2 + nm2);
                         }
                     }
+                }
+            };
+            {
+                using T_ = std::true_type; using F_ = std::false_type;
+                if (has_r && has_x) { if (a.bnb_act) res_bnb(T_{}, T_{}, T_{}); else res_bnb(T_{}, T_{}, F_{}); }
+                else if (has_x) { if (a.bnb_act) res_bnb(F_{}, T_{}, T_{}); else res_bnb(F_{}, T_{}, F_{}); }
+                else if (has_r) res_bnb(T_{}, F_{}, F_{});
             }
 #pragma unroll
             for (int ms = 0; ms < 2; ++ms)
@@ -674,13 +707,18 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v8), ry, vo, 0, 0);
             }
             }
+            TT(8 + 6 * it);
             __syncthreads();
+            TT(9 + 6 * it);
         }
+        TT(3);
     }
 
     // ---- one row of BatchNorm-backward partial sums per workgroup ----------------------------------------------------
     if (has_x) {
         if (consumer) {
+            float rs1 = rs1v[0] + rs1v[1], rs2 = rs2v[0] + rs2v[1];
+            const float rsl = rslv[0] + rslv[1];
             rs1 += __shfl_xor(rs1, 32);
             rs2 += __shfl_xor(rs2, 32);
             if (kk == 0) { red[(wave * 32 + l31) * 2] = rs1; red[(wave * 32 + l31) * 2 + 1] = rs2; }
@@ -696,6 +734,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
         }
         if (tid == 0) wk[128] = (red[256] + red[257]) + (red[258] + red[259]);
     }
+    TT(63);
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------
