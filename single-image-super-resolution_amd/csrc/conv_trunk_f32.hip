@@ -329,16 +329,24 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[i] += rv[i];
                 }
-                if (has_x) {
+                if (has_x) {                                           // (two straight-line versions, not a branch per element)
+                    if (a.bnb_act) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        float gv = acc[i];
-                        if (a.bnb_act) {
+                        for (int i = 0; i < 16; ++i) {
+                            float gv = acc[i];
                             const float z = b_sc * xv[i] + b_sf;
-                            if (!(z > 0.f)) { rsl += gv * z; gv *= b_slope; }
+                            const bool neg = !(z > 0.f);
+                            rsl += neg ? gv * z : 0.f;
+                            gv = neg ? gv * b_slope : gv;
+                            rs1 += gv;
+                            rs2 += gv * ((xv[i] - b_mu) * b_is);
                         }
-                        rs1 += gv;
-                        rs2 += gv * ((xv[i] - b_mu) * b_is);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            rs1 += acc[i];
+                            rs2 += acc[i] * ((xv[i] - b_mu) * b_is);
+                        }
                     }
                 }
                 if (a.stat_part != nullptr) {
