@@ -332,7 +332,10 @@ __device__ __forceinline__ void bn_finalize_in_kernel(const BnFinArgs& f, double
     const int c = threadIdx.x & 63, split = threadIdx.x >> 6;
     const double K = (double)f.stat[c];
     double N = 0.0, S = 0.0, Q = 0.0;
-#pragma unroll 4
+#ifndef BNFIN_UNROLL
+#define BNFIN_UNROLL 4
+#endif
+#pragma unroll BNFIN_UNROLL
     for (int t = split; t < f.rows; t += 8) {
         const double nb = (double)f.cnt[t];
         const double dm = (double)f.stat[(int64_t)t * 128 + c] - K;
