@@ -84,6 +84,9 @@ struct TrunkArgs {
     int tiles_x, per_img, total;          // tiles per row, per image, in all
     uint32_t m_tiles_x, m_per_img;        // reciprocals (fdiv_magic)
     int pro;
+    // forward role with Cout = 256 + PixelShuffle(2) store (the generator's upscale conv, model_generator.py:43-48): 4 groups
+    // of 64 packed couts = the 4 shuffle phases; workgroup b serves group b % 4 on tile stream b / 4
+    int glog, cout_pad, shuffle;
 };
 
 // The producers are bound by VALU issue (they share a SIMD's issue port with the consumer's MFMAs), so everything about
@@ -174,6 +177,8 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     const int l31 = lane & 31, kk = lane >> 5;
     const int h = wave & 1, g = (wave >> 1) & 1;
     const unsigned xbytes = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * 128u;
+    const int cg = blockIdx.x & ((1 << a.glog) - 1);                    // cout group (shuffle phase) of this workgroup
+    const int t_first = blockIdx.x >> a.glog, t_step = gridDim.x >> a.glog;
     auto tile_coords = [&](int T, int& n, int& ty, int& tx) {
         n = fdiv(T, a.m_per_img);
         const int rem = T - n * a.per_img;
@@ -209,19 +214,20 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     // (role state is set up INSIDE the role branches below: set up ahead of the split, every register of both roles
     // meets in one merge block and the allocator spills weights at load time)
     auto init_consumer = [&]() {
-        const __amdgpu_buffer_rsrc_t wrs = bf_rsrc(a.wpk, 2u * 64u * 9u * 32u * 2u);
-        const int co = 32 * h + l31;
+        const __amdgpu_buffer_rsrc_t wrs = bf_rsrc(a.wpk, 2u * (unsigned)a.cout_pad * 9u * 32u * 2u);
+        const int co = 64 * cg + 32 * h + l31;                              // packed cout
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned off = (unsigned)((((j >> 1) * 64 + co) * 9 + t) * 32 + (j & 1) * 16 + 8 * kk) * 2u;
+                const unsigned off = (unsigned)((((j >> 1) * a.cout_pad + co) * 9 + t) * 32 + (j & 1) * 16 + 8 * kk) * 2u;
                 bw[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
             }
         // A operand of sub-tile ms: lane (l31, kk) = pixel (tile row 4g + 2ms + (l31 >> 4), column l31 & 15), channels 8kk..
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) a_base[ms] = (4 * g + 2 * ms + (l31 >> 4)) * TK_RP + (l31 & 15) * TK_PSB + kk * 16;
-        bv = a.bias != nullptr ? a.bias[32 * h + l31] : 0.f;
+        // (bias is in ORIGINAL channel order: packed cout (phase cg, channel c) of a shuffled layer = original c * 4 + cg)
+        bv = a.bias != nullptr ? a.bias[a.shuffle ? (32 * h + l31) * 4 + cg : 32 * h + l31] : 0.f;
     };
     auto init_producer = [&]() {
         slope = a.slope_p ? a.slope_p[0] : a.slope;
@@ -284,10 +290,10 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     if (!consumer) {
         // ---- producers: tile T + 1 into the other buffer while the consumers work on tile T ------------------------------
         init_producer();
-        int T = blockIdx.x;
+        int T = t_first;
         init_constants();
         issue(T, stA);
-        issue(T + gridDim.x, stB);
+        issue(T + t_step, stB);
         if (T < a.total) commit(lds, stA);
         TTP(2);
         __syncthreads();
@@ -296,29 +302,29 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
         [[maybe_unused]] int it = 0;
         while (T < a.total) {
             TTP(4 + 6 * it);
-            issue(T + 2 * gridDim.x, stA);
+            issue(T + 2 * t_step, stA);
             TTP(5 + 6 * it);
-            if (T + (int)gridDim.x < a.total) commit(lds + (cur ^ 1) * TK_HALO_BYTES, stB);
+            if (T + t_step < a.total) commit(lds + (cur ^ 1) * TK_HALO_BYTES, stB);
             TTP(8 + 6 * it);
             __syncthreads();
             TTP(9 + 6 * it);
-            T += gridDim.x; cur ^= 1; ++it;
+            T += t_step; cur ^= 1; ++it;
             if (T >= a.total) break;
             TTP(4 + 6 * it);
-            issue(T + 2 * gridDim.x, stB);
+            issue(T + 2 * t_step, stB);
             TTP(5 + 6 * it);
-            if (T + (int)gridDim.x < a.total) commit(lds + (cur ^ 1) * TK_HALO_BYTES, stA);
+            if (T + t_step < a.total) commit(lds + (cur ^ 1) * TK_HALO_BYTES, stA);
             TTP(8 + 6 * it);
             __syncthreads();
             TTP(9 + 6 * it);
-            T += gridDim.x; cur ^= 1; ++it;
+            T += t_step; cur ^= 1; ++it;
         }
     } else {
         init_consumer();
         TT(2);
         __syncthreads();
         int cur = 0, it = 0;
-        for (int T = blockIdx.x; T < a.total; T += gridDim.x, cur ^= 1, ++it) {
+        for (int T = t_first; T < a.total; T += t_step, cur ^= 1, ++it) {
             TT(4 + 6 * it);
             {
             // ---- consumer: MFMA phase (2 sub-tiles x 9 taps x 4 K-steps; every A address is base + immediate) ... -------
@@ -351,7 +357,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
             }
             TT(6 + 6 * it);
             // ---- ... and epilogue: bias, statistics, bf16, transposed store -------------------------------------------------
-            const __amdgpu_buffer_rsrc_t ry = bf_rsrc(a.y, xbytes);
+            const __amdgpu_buffer_rsrc_t ry = bf_rsrc(a.y, a.shuffle ? 4u * xbytes : xbytes);
             int n, ty, tx;
             tile_coords(T, n, ty, tx);
             if (a.stat_part != nullptr) {
@@ -388,8 +394,10 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
                 const __bf16* src = my_out + (8 * grp + tq) * TK_YS + 16 * pb + 4 * tp;
                 const s16x4 lo = lds_tr16(src), hi = lds_tr16(src + 4 * TK_YS);
                 const s16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                const unsigned vo = (unsigned)(((n * a.H + ty * TK_TH + 4 * g + pb) * a.W + tx * TK_TW + (lane & 15)) * 128 +
-                                               (32 * h + 8 * grp) * 2);
+                const int oy = ty * TK_TH + 4 * g + pb, ox = tx * TK_TW + (lane & 15);
+                // PixelShuffle(2) on store: phase cg = (i, j) of this workgroup's couts lands on pixel (2 oy + i, 2 ox + j)
+                const unsigned vo = a.shuffle ? (unsigned)(((n * 2 * a.H + 2 * oy + (cg >> 1)) * 2 * a.W + 2 * ox + (cg & 1)) * 128 + (32 * h + 8 * grp) * 2)
+                                              : (unsigned)(((n * a.H + oy) * a.W + ox) * 128 + (32 * h + 8 * grp) * 2);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v8), ry, vo, 0, 0);
             }
             }
@@ -738,6 +746,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------
+static int trunk_groups(const SisrConvDesc* d) { return d->Cout == 256 ? 4 : 1; }
 static int trunk_grid(const SisrConvDesc* d) {
     const int total = d->N * (d->H / TK_TH) * (d->W / TK_TW);
     static int cus = 0;                         // (one process drives one GPU: queried once)
@@ -753,18 +762,27 @@ static int trunk_grid(const SisrConvDesc* d) {
     int per_cu = 1;
     if (const char* e = getenv("SISR_TRUNK_WG_PER_CU")) per_cu = std::max(1, std::min(2, atoi(e)));
     n_cu *= per_cu;
+    const int G = trunk_groups(d);                 // cout groups: each tile stream is served by G workgroups
+    n_cu = std::max(1, n_cu / G);
     const int rounds = (total + n_cu - 1) / n_cu;
-    return (total + rounds - 1) / rounds;
+    return G * ((total + rounds - 1) / rounds);
 }
 
 // 1 when this descriptor (geometry + storage flags + fusions requested) can run on the trunk kernel
 extern "C" int sisr_conv2d_trunk_eligible(const SisrConvDesc* d) {
     const char* sw = getenv("SISR_TRUNK");                      // A/B switch: SISR_TRUNK=0 keeps the generic kernel
     if (!d || (sw && sw[0] == '0')) return 0;
-    if (d->Cin != 64 || d->Cout != 64 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
-    if (d->x_mode != SISR_X_NHWC || d->y_mode != SISR_Y_NHWC || !d->x_bf16 || !d->y_bf16) return 0;
+    if (d->Cin != 64 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
+    // Cout = 64 (trunk), or 256 stored through PixelShuffle(2) -- the upscale conv, forward role without statistics
+    const char* swu = getenv("SISR_TRUNK_UP");                 // A/B switch for the upscale conv alone
+    const bool up = !(swu && swu[0] == '0') && d->Cout == 256 && d->y_mode == SISR_Y_NHWC_SHUFFLE2 && d->plan.CoutPad == 256 && !d->stat_part && !d->res &&
+                    !d->bnb_part && d->pro_mode != SISR_PRO_RES_AFFINE && !d->fin_stat &&
+                    (d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT);
+    if (!up && (d->Cout != 64 || d->y_mode != SISR_Y_NHWC)) return 0;
+    if (d->x_mode != SISR_X_NHWC || !d->x_bf16 || !d->y_bf16) return 0;
     if (d->Ho != d->H || d->Wo != d->W || (d->H % TK_TH) || (d->W % TK_TW)) return 0;
-    if (d->y_sy != 1 || d->y_sx != 1 || d->y_oy || d->y_ox || d->y_H != d->Ho || d->y_W != d->Wo) return 0;
+    if (!up && (d->y_sy != 1 || d->y_sx != 1 || d->y_oy || d->y_ox || d->y_H != d->Ho || d->y_W != d->Wo)) return 0;
+    if (up && (int64_t)d->N * d->H * d->W * 512 >= (1ll << 31)) return 0;
     if (d->epi_act != SISR_EPI_NONE) return 0;
     if ((int64_t)d->N * d->H * d->W * 128 >= (1ll << 31)) return 0;
     if (d->N * (d->H / TK_TH) * (d->W / TK_TW) >= 65536) return 0;
@@ -829,6 +847,7 @@ int sisr_conv2d_trunk_launch(const SisrConvDesc* d, hipStream_t st) {
     a.tiles_x = d->W / TK_TW; a.per_img = (d->H / TK_TH) * a.tiles_x; a.total = d->N * a.per_img;
     a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);
     a.pro = d->pro_mode;
+    a.glog = d->Cout == 256 ? 2 : 0; a.cout_pad = d->Cout == 256 ? 256 : 64; a.shuffle = d->y_mode == SISR_Y_NHWC_SHUFFLE2 ? 1 : 0;
     a.res = d->res; a.bnb_x = d->bnb_x; a.bnb_scale = d->bnb_scale; a.bnb_shift = d->bnb_shift; a.bnb_mean = d->bnb_mean;
     a.bnb_invstd = d->bnb_invstd; a.bnb_slope_p = d->bnb_slope_p; a.bnb_slope = d->bnb_slope; a.bnb_act = d->bnb_act;
     a.bnb_part = d->bnb_part;

@@ -753,3 +753,34 @@ def test_trunk_kernels_form_the_skip_sum_in_their_staging(E, L, shape, res_slope
         assert not E.trunk_takes_skip_sum(p, resid, t)
     finally:
         E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('pro', ['none', 'act'])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (1, 96, 96)])
+def test_trunk_kernel_upscale_conv_with_pixel_shuffle_store(E, L, shape, pro, monkeypatch):
+    """conv_trunk.hip forward role with Cout = 256 stored through PixelShuffle(2) (the generator's upscale conv,
+    model_generator.py:43-48: four cout groups = the four shuffle phases) against the generic bf16 kernel and against
+    F.pixel_shuffle(F.conv2d(...)) -- bias in original channel order included"""
+    n, h, w = shape
+    monkeypatch.setenv('SISR_STORAGE', 'bf16')
+    x = (_rand((n, 64, h, w), 181) * 2.0).bfloat16().float()
+    wt = _rand((256, 64, 3, 3), 182, (1.0 / 576) ** 0.5 * 1.7)
+    b = _rand((256,), 183, 0.1)
+    slope = torch.tensor([0.25])
+    xin = F.leaky_relu(x, 0.25) if pro == 'act' else x
+    y_ref = F.pixel_shuffle(F.conv2d(xin, wt, b, padding=1), 2)
+    E.set_precision('bf16')
+    try:
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 256, 3, 1, 1, shuffle2=True))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        xd = nhwc(x).cuda().bfloat16()
+        op = E.Operand.plain(xd) if pro == 'none' else E.Operand.act(xd, slope.cuda())
+        out = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_TRUNK', sw)
+            out[sw] = E.conv_forward(p, op, bias=ref.bias)[0].float()
+        assert tuple(out['1'].shape) == (n, 2 * h, 2 * w, 64)
+        assert maxrel(nchw(out['1']), y_ref) < BF16_TOL
+        assert maxrel(out['1'], out['0']) < 6e-3
+    finally:
+        E.set_precision('fp32')
