@@ -121,7 +121,7 @@ __device__ __forceinline__ unsigned tile_edge_mask(int ty, int tx, int tiles_y, 
 }
 
 // prologue of 8 consecutive channels of one pixel: a (and b) hold 8 bf16; returns 8 bf16 packed
-template <int PRO, bool EASY>
+template <int PRO, int EASY>
 __device__ __forceinline__ u32x4 trunk_apply8(u32x4 a, u32x4 b, const f32x8& ka, const f32x8& kb, const f32x8& kd,
                                               const f32x8& ks, const f32x8& kt, float slope, bool ok) {
     if (PRO == SISR_PRO_NONE) return a;                       // zeros outside the image already (hardware OOB)
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
         }
     };
     auto commit_t = [&](auto easy, unsigned char* buf, const Stage& st) {
-        constexpr bool EASY = decltype(easy)::value;
+        constexpr int EASY = decltype(easy)::value;
         const __amdgpu_buffer_rsrc_t ro = bf_rsrc(TWO ? a.x_out : a.x1, xbytes);
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
@@ -278,8 +278,10 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
         }
     };
     auto commit = [&](unsigned char* buf, const Stage& st) {
-        if (easy_slope) commit_t(std::true_type{}, buf, st);
-        else commit_t(std::false_type{}, buf, st);
+        // (the skip sum of every block but the first has no activation on its residual: slope 1, nothing to compute)
+        if (TWO && slope == 1.f) commit_t(std::integral_constant<int, 2>{}, buf, st);
+        else if (easy_slope) commit_t(std::integral_constant<int, 1>{}, buf, st);
+        else commit_t(std::integral_constant<int, 0>{}, buf, st);
     };
     __bf16* my_out = out_img + (wave & 3) * (32 * TK_YS);
     const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
@@ -560,7 +562,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
 #pragma unroll
         for (int k = 0; k < TK_ITEMS; ++k) {
             const bool ok = ((bad >> (5 * k)) & 31u) == 0u;
-            const u32x4 v = trunk_apply8<PRO, false>(ra[k], rb[k], ka, kb, kd, ks, kt, slope, ok);
+            const u32x4 v = trunk_apply8<PRO, 0>(ra[k], rb[k], ka, kb, kd, ks, kt, slope, ok);
             // (only the last item of a thread can lie beyond the 180 halo pixels)
             if (k < TK_ITEMS - 1 || !((hm.flags >> (5 * k + 4)) & 1u)) *reinterpret_cast<u32x4*>(buf + hm.ldso[k]) = v;
         }

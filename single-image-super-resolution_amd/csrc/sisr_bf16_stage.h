@@ -38,8 +38,10 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 }
 // leaky ReLU.  EASY (0 <= slope <= 1, every slope this model family uses): max(v, slope v), one multiply and one
 // v_max (as an instruction: fmaxf() adds a canonicalising v_max per operand); otherwise compare and select.
-template <bool EASY>
+// EASY == 2: slope is exactly 1 (no activation on this operand): the identity.
+template <int EASY>
 __device__ __forceinline__ float lrelu_t(float v, float slope) {
+    if (EASY == 2) return v;
     if (EASY) {
         float r;
         const float sv = slope * v;

@@ -72,7 +72,7 @@ __device__ __forceinline__ bf16x8 wt_frag(const unsigned char* p) {
 
 // x prologue of one thread's staged halo items: lrelu(a x + d) (a = 1, d = 0, slope = 1 degenerate to ACT / NONE), zero
 // outside the image; dst0 = the thread's first LDS slot, item k sits 32 pixels further
-template <bool EASY>
+template <int EASY>
 __device__ __forceinline__ void wt_commit_x(const u32x4 (&sx)[WT_XITEMS], unsigned bad, unsigned xflags, const float* kst, int oct,
                                             float xslope, unsigned char* dst0) {
     const f32x8 ka = *reinterpret_cast<const f32x8*>(kst + oct * 8), kd = *reinterpret_cast<const f32x8*>(kst + 64 + oct * 8);
@@ -260,8 +260,13 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
         };
         auto commit_x = [&](int b) {
             unsigned char* dst0 = lds + b * (WT_XBYTES + WT_DBYTES) + xlds0;
-            if (easy_slope) wt_commit_x<true>(sx, bad, xflags, kst, oct, xslope, dst0);
-            else wt_commit_x<false>(sx, bad, xflags, kst, oct, xslope, dst0);
+            if (a.xpro == SISR_PRO_NONE) {
+                // no prologue: the staged bf16 items go to LDS as they are (outside the image the loads returned zeros)
+#pragma unroll
+                for (int k = 0; k < WT_XITEMS; ++k)
+                    if (k < WT_XITEMS - 1 || !((xflags >> (5 * k + 4)) & 1u)) *reinterpret_cast<u32x4*>(dst0 + k * 32 * WT_PS) = sx[k];
+            } else if (easy_slope) wt_commit_x<1>(sx, bad, xflags, kst, oct, xslope, dst0);
+            else wt_commit_x<0>(sx, bad, xflags, kst, oct, xslope, dst0);
         };
         WTT(0);
         if ((int)blockIdx.x < a.total) {
