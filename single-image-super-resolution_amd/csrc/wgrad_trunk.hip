@@ -63,6 +63,10 @@ struct WTrunkArgs {
     int tiles_x, per_img, total;
     uint32_t m_tiles_x, m_per_img;
     int xpro;
+    // Cout = 256 with the gradient stored shuffled (the upscale conv, model_generator.py:43-48): four cout groups = the four
+    // PixelShuffle phases, workgroup b serves group b % 4 on tile stream b / 4; the gradient operand of group (i, j) is the
+    // strided view pixel (2 y + i, 2 x + j) of the [N][2H][2W][64] tensor.  A stream's four workgroups share one slab.
+    int glog, cout_pad, gshuffle;
 };
 
 __device__ __forceinline__ bf16x8 wt_frag(const unsigned char* p) {
@@ -104,6 +108,8 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
     const int l31 = lane & 31;
     const int h = wave & 1, gq = (wave >> 1) & 1;             // consumer: output-channel half, input-channel chunk
     const unsigned xbytes = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * 128u;
+    const int cg = blockIdx.x & ((1 << a.glog) - 1);                    // cout group (shuffle phase) of this workgroup
+    const int t_first = blockIdx.x >> a.glog, t_step = gridDim.x >> a.glog;
     auto tile_coords = [&](int T, int& n, int& ty, int& tx) {
         n = fdiv(T, a.m_per_img);
         const int rem = T - n * a.per_img;
@@ -127,7 +133,7 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
     // partly beyond the 180 halo pixels) or of the tile (gradient, 4 items), channel octet pt % 8.  Both roles are bound by
     // VALU issue while they stage, so everything about an item that does not depend on the tile is computed once.
     const int pt = tid & 255, oct = tid & 7, m0 = pt >> 3;
-    float* sl = a.slab + (int64_t)blockIdx.x * a.slab_stride;
+    float* sl = a.slab + (int64_t)t_first * a.slab_stride;
 
     // Two role-specific tile loops with matching barrier counts (a barrier only counts arriving waves; written as one loop
     // with a role branch inside, the allocator carries the accumulators through the producers' code and spills them).
@@ -143,23 +149,35 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
         const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x8 bsum = zero8;                                          // bias gradient: this thread's 8 channels, its pixels
         f32x8 qa, qb, qd, qs = zero8, qt = zero8;
+        if (GPRO != SISR_PRO_ACT_BWD) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            qa[j] = a.qa[oct * 8 + j]; qb[j] = a.qb[oct * 8 + j]; qd[j] = a.qd[oct * 8 + j];
-            if (GPRO == SISR_PRO_BNACT_BWD) { qs[j] = a.qs[oct * 8 + j]; qt[j] = a.qt[oct * 8 + j]; }
+            for (int j = 0; j < 8; ++j) {
+                qa[j] = a.qa[oct * 8 + j]; qb[j] = a.qb[oct * 8 + j]; qd[j] = a.qd[oct * 8 + j];
+                if (GPRO == SISR_PRO_BNACT_BWD) { qs[j] = a.qs[oct * 8 + j]; qt[j] = a.qt[oct * 8 + j]; }
+            }
+        } else {
+            qa = zero8; qb = zero8; qd = zero8;
         }
-        const int grel0 = ((m0 >> 4) * a.W + (m0 & 15)) * 128 + oct * 16;  // tile pixel m0 + 32 k: two rows further down per item
+        // tile pixel m0 + 32 k: two rows further down per item; a shuffled gradient is read through the strided view of
+        // this workgroup's phase (pixel pitch 2, row pitch 2 * 2W)
+        const int gsc = a.gshuffle ? 2 : 1, gW = gsc * a.W;
+        const int grel0 = ((m0 >> 4) * gsc * gW + (m0 & 15) * gsc) * 128 + oct * 16;
+        const int gstep = 2 * gsc * gW * 128;
+        const unsigned gbytes = (unsigned)(gsc * gsc) * xbytes;
         const int glds0 = WT_XBYTES + m0 * WT_PS + oct * 16;
         // (always executed, so that the tile loop below stays free of control flow around loads: past the last tile the
         // offsets are out of range, which costs an instruction and no memory traffic.  With a branch around the loads the
         // compiler's wait-count bookkeeping gives up at the merge and drains every load before the next commit.)
         auto issue_g = [&](int T, GStage& st) {
-            const __amdgpu_buffer_rsrc_t r1 = bf_rsrc(a.g1, xbytes), r2 = bf_rsrc(a.g2, xbytes);
-            int ty, tx;
-            const unsigned origin = T < a.total ? tile_origin(T, ty, tx) : 0x80000000u;   // (a scalar select, not a branch)
+            const __amdgpu_buffer_rsrc_t r1 = bf_rsrc(a.g1, gbytes), r2 = bf_rsrc(a.g2, gbytes);
+            int n, ty, tx;
+            tile_coords(T, n, ty, tx);
+            const unsigned org = (unsigned)(((n * gsc * a.H + gsc * ty * WT_TH + (a.gshuffle ? cg >> 1 : 0)) * gW +
+                                             gsc * tx * WT_TW + (a.gshuffle ? cg & 1 : 0)) * 128);
+            const unsigned origin = T < a.total ? org : 0x80000000u;                      // (a scalar select, not a branch)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const unsigned voff = origin + (unsigned)(grel0 + k * 2 * a.W * 128);
+                const unsigned voff = origin + (unsigned)(grel0 + k * gstep);
                 st.g1[k] = __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0);
                 st.g2[k] = __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0);
             }
@@ -179,8 +197,14 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
                         g0 = qs[2 * j] * b0 + qt[2 * j] > 0.f ? a0 : gslope * a0;
                         g1 = qs[2 * j + 1] * b1 + qt[2 * j + 1] > 0.f ? a1 : gslope * a1;
                     }
-                    const float r0 = qa[2 * j] * g0 + qb[2 * j] * b0 + qd[2 * j];
-                    const float r1 = qa[2 * j + 1] * g1 + qb[2 * j + 1] * b1 + qd[2 * j + 1];
+                    float r0, r1;
+                    if (GPRO == SISR_PRO_ACT_BWD) {                    // act'(pre-activation) * gradient
+                        r0 = b0 > 0.f ? a0 : gslope * a0;
+                        r1 = b1 > 0.f ? a1 : gslope * a1;
+                    } else {
+                        r0 = qa[2 * j] * g0 + qb[2 * j] * b0 + qd[2 * j];
+                        r1 = qa[2 * j + 1] * g1 + qb[2 * j + 1] * b1 + qd[2 * j + 1];
+                    }
                     bsum[2 * j] += r0; bsum[2 * j + 1] += r1;
                     o[j] = pack_bf16x2(r0, r1);
                 }
@@ -189,9 +213,9 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
         };
         // two register sets: the loads of tile T + 2 fly while tile T + 1 is transformed.  The loop is unrolled by two so
         // that each set has a fixed name in each half.
-        int T = blockIdx.x;
+        int T = t_first;
         issue_g(T, gA);
-        issue_g(T + gridDim.x, gB);
+        issue_g(T + t_step, gB);
         if (T < a.total) commit_g(0, gA);
         WTTP(2);
         __syncthreads();
@@ -199,22 +223,22 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
         [[maybe_unused]] int it = 0;
         while (T < a.total) {
             WTTP(4 + 6 * it);
-            issue_g(T + 2 * gridDim.x, gA);                       // gB holds tile T + grid
+            issue_g(T + 2 * t_step, gA);                       // gB holds tile T + grid
             WTTP(5 + 6 * it);
-            if (T + (int)gridDim.x < a.total) commit_g(cur ^ 1, gB);
+            if (T + t_step < a.total) commit_g(cur ^ 1, gB);
             WTTP(8 + 6 * it);
             __syncthreads();      // the next tile's images are complete; the consumers have finished reading this one
             WTTP(9 + 6 * it);
-            T += gridDim.x; cur ^= 1; ++it;
+            T += t_step; cur ^= 1; ++it;
             if (T >= a.total) break;
             WTTP(4 + 6 * it);
-            issue_g(T + 2 * gridDim.x, gB);                       // gA holds tile T + grid
+            issue_g(T + 2 * t_step, gB);                       // gA holds tile T + grid
             WTTP(5 + 6 * it);
-            if (T + (int)gridDim.x < a.total) commit_g(cur ^ 1, gA);
+            if (T + t_step < a.total) commit_g(cur ^ 1, gA);
             WTTP(8 + 6 * it);
             __syncthreads();
             WTTP(9 + 6 * it);
-            T += gridDim.x; cur ^= 1; ++it;
+            T += t_step; cur ^= 1; ++it;
         }
         if (a.bias_slab != nullptr) *reinterpret_cast<f32x8*>(lds + pt * 32) = bsum;     // the images are free by now
     } else {
@@ -269,14 +293,14 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
             else wt_commit_x<0>(sx, bad, xflags, kst, oct, xslope, dst0);
         };
         WTT(0);
-        if ((int)blockIdx.x < a.total) {
-            issue_x(blockIdx.x);
+        if (t_first < a.total) {
+            issue_x(t_first);
             commit_x(0);
         }
         __syncthreads();
         int cur = 0, it = 0;
-        for (int T = blockIdx.x; T < a.total; T += gridDim.x, cur ^= 1, ++it) {
-            const int Tn = T + gridDim.x;
+        for (int T = t_first; T < a.total; T += t_step, cur ^= 1, ++it) {
+            const int Tn = T + t_step;
             WTT(4 + 6 * it);
             if (Tn < a.total) issue_x(Tn);
             // halo rows R = 0 .. 9: the three column shifts of row R against the gradient rows R, R - 1, R - 2
@@ -309,7 +333,7 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sl[((gq * 9 + t) * 32 + mfma_row(i, lane)) * 64 + 32 * h + l31] = acc[t][i];
+            for (int i = 0; i < 16; ++i) sl[((gq * 9 + t) * 32 + mfma_row(i, lane)) * a.cout_pad + 64 * cg + 32 * h + l31] = acc[t][i];
     }
     if (a.bias_slab != nullptr) {                       // ... and its bias row
         __syncthreads();
@@ -318,7 +342,7 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
             const int o8 = tid >> 3, j = tid & 7;
             float s = 0.f;
             for (int i = 0; i < 32; ++i) s += bs[(o8 + 8 * i) * 8 + j];                  // fixed order: deterministic
-            a.bias_slab[(int64_t)blockIdx.x * a.slab_stride + tid] = s;
+            a.bias_slab[(int64_t)t_first * a.slab_stride + 64 * cg + tid] = s;
         }
     }
     WTT(63);
@@ -335,8 +359,10 @@ static int wtrunk_grid(const SisrWgradDesc* d) {
         else
             cus = 256;
     }
-    const int rounds = (total + cus - 1) / cus;
-    return (total + rounds - 1) / rounds;       // equal shares
+    const int G = d->Cout == 256 ? 4 : 1;       // cout groups: each tile stream is served by G workgroups
+    const int slots = std::max(1, cus / G);
+    const int rounds = (total + slots - 1) / slots;
+    return G * ((total + rounds - 1) / rounds);  // equal shares
 }
 
 extern "C" int sisr_wgrad_trunk_eligible(const SisrWgradDesc* d) {
@@ -344,21 +370,27 @@ extern "C" int sisr_wgrad_trunk_eligible(const SisrWgradDesc* d) {
     if (!d || (sw && sw[0] == '0')) return 0;
     const char* sw2 = getenv("SISR_TRUNK_WGRAD");
     if (sw2 && sw2[0] == '0') return 0;
-    if (d->Cin != 64 || d->Cout != 64 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
-    if (d->x_mode != SISR_X_NHWC || d->g_mode != SISR_X_NHWC || !d->x_bf16 || !d->g_bf16) return 0;
+    if (d->Cin != 64 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
+    // Cout = 64 (trunk: BatchNorm-backward gradient prologues), or 256 with the gradient stored shuffled and an
+    // activation-backward prologue -- the upscale conv
+    const char* swu = getenv("SISR_TRUNK_UP");                 // A/B switch for the upscale conv alone
+    const bool up = !(swu && swu[0] == '0') && d->Cout == 256 && d->g_mode == SISR_X_NHWC_UNSHUFFLE2 && d->CoutPad == 256 &&
+                    d->gpro_mode == SISR_PRO_ACT_BWD && (int64_t)d->N * d->H * d->W * 512 < (1ll << 31);
+    if (!up && (d->Cout != 64 || d->g_mode != SISR_X_NHWC || d->CoutPad != 64)) return 0;
+    if (d->x_mode != SISR_X_NHWC || !d->x_bf16 || !d->g_bf16) return 0;
     if (d->Ho != d->H || d->Wo != d->W || (d->H % WT_TH) || (d->W % WT_TW)) return 0;
-    if (d->CoutPad != 64 || d->n_chunk != 2 || d->KROWP != 9 * 32) return 0;
+    if (d->n_chunk != 2 || d->KROWP != 9 * 32) return 0;
     if ((int64_t)d->N * d->H * d->W * 128 >= (1ll << 31)) return 0;
     if (d->N * (d->H / WT_TH) * (d->W / WT_TW) >= 65536) return 0;
     const bool xp = d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT;
-    const bool gp = d->gpro_mode == SISR_PRO_BNBWD || d->gpro_mode == SISR_PRO_BNACT_BWD;
+    const bool gp = up || d->gpro_mode == SISR_PRO_BNBWD || d->gpro_mode == SISR_PRO_BNACT_BWD;
     return xp && gp ? 1 : 0;
 }
 
 // slabs a launch of this descriptor writes (rows of `slab` at slab_stride): one per workgroup
 extern "C" int sisr_wgrad_bf16_slabs(const SisrWgradDesc* d) {
     if (!d) return SISR_E_BADARG;
-    return sisr_wgrad_trunk_eligible(d) ? wtrunk_grid(d) : d->n_slabs;
+    return sisr_wgrad_trunk_eligible(d) ? wtrunk_grid(d) / (d->Cout == 256 ? 4 : 1) : d->n_slabs;
 }
 
 template <int GPRO>
@@ -380,7 +412,8 @@ static int launch_wtrunk(const WTrunkArgs& a, int grid, hipStream_t st) {
 int sisr_wgrad_trunk_launch(const SisrWgradDesc* d, hipStream_t st) {
     if (operand_needs_x2(d->gpro_mode) && !d->g2) return SISR_E_BADARG;
     if (d->pro_mode == SISR_PRO_AFFINE_ACT && (!d->pa || !d->pd)) return SISR_E_BADARG;
-    if (!d->qa || !d->qb || !d->qd || (d->gpro_mode == SISR_PRO_BNACT_BWD && (!d->qs || !d->qt))) return SISR_E_BADARG;
+    if (d->gpro_mode != SISR_PRO_ACT_BWD && (!d->qa || !d->qb || !d->qd || (d->gpro_mode == SISR_PRO_BNACT_BWD && (!d->qs || !d->qt))))
+        return SISR_E_BADARG;
     WTrunkArgs a;
     a.x1 = d->x1; a.g1 = d->g1; a.g2 = d->g2;
     a.pa = d->pa; a.pd = d->pd; a.xslope_p = d->pro_slope_p; a.xslope = d->pro_slope;
@@ -391,7 +424,9 @@ int sisr_wgrad_trunk_launch(const SisrWgradDesc* d, hipStream_t st) {
     a.tiles_x = d->W / WT_TW; a.per_img = (d->H / WT_TH) * a.tiles_x; a.total = d->N * a.per_img;
     a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);
     a.xpro = d->pro_mode;
+    a.glog = d->Cout == 256 ? 2 : 0; a.cout_pad = d->Cout == 256 ? 256 : 64; a.gshuffle = d->g_mode == SISR_X_NHWC_UNSHUFFLE2 ? 1 : 0;
     const int grid = wtrunk_grid(d);
+    if (d->gpro_mode == SISR_PRO_ACT_BWD) return launch_wtrunk<SISR_PRO_ACT_BWD>(a, grid, st);
     if (d->gpro_mode == SISR_PRO_BNBWD) return launch_wtrunk<SISR_PRO_BNBWD>(a, grid, st);
     return launch_wtrunk<SISR_PRO_BNACT_BWD>(a, grid, st);
 }

@@ -784,3 +784,43 @@ def test_trunk_kernel_upscale_conv_with_pixel_shuffle_store(E, L, shape, pro, mo
         assert maxrel(out['1'], out['0']) < 6e-3
     finally:
         E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 32), (1, 96, 96)])
+def test_trunk_kernel_upscale_conv_weight_gradient(E, L, shape, monkeypatch):
+    """wgrad_trunk.hip with Cout = 256 and the gradient stored shuffled (the upscale conv: four cout groups = the four
+    PixelShuffle phases, activation-backward prologue on the strided view of each phase) against the generic bf16 kernel
+    and against autograd through conv -> pixel_shuffle -> PReLU"""
+    n, h, w = shape
+    monkeypatch.setenv('SISR_STORAGE', 'bf16')
+    bf = lambda t: t.bfloat16().float()
+    x = bf(_rand((n, 64, h, w), 191) * 2.0)
+    wt = _rand((256, 64, 3, 3), 192, (1.0 / 576) ** 0.5 * 1.7)
+    b = _rand((256,), 193, 0.1)
+    slope = torch.tensor([0.25])
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pre_ref = F.pixel_shuffle(F.conv2d(x, wr, br, padding=1), 2)
+    pre = bf(pre_ref.detach())                                   # the stored pre-activation (bf16 NHWC in the engine)
+    g = bf(_rand((n, 64, 2 * h, 2 * w), 194))                    # gradient arriving at the PReLU output
+    gpre = torch.where(pre > 0, g, 0.25 * g)
+    pre_ref.backward(gpre)
+    E.set_precision('bf16')
+    try:
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 256, 3, 1, 1, shuffle2=True))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        x_op = E.Operand.plain(nhwc(x).cuda().bfloat16())
+        gd, pd_ = nhwc(g).cuda().bfloat16(), nhwc(pre).cuda().bfloat16()
+        dy_op = E.Operand(gd, (n, h, w, 256), pro=L.PRO_ACT_BWD, mode=L.X_UNSHUFFLE2, x2=pd_, slope=slope.cuda())
+        red = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_TRUNK_UP', sw)
+            red[sw] = E.conv_wgrad(p, x_op, dy_op)
+        assert maxrel(red['1'], red['0']) < 2e-3
+        wg = E.WeightGradBatch()
+        wg.add(p, red['1'])
+        gw, gb = wg.run()[id(ref)]
+        assert maxrel(gw, wr.grad) < BF16_TOL and maxrel(gb, br.grad) < BF16_TOL
+        monkeypatch.setenv('SISR_TRUNK_UP', '1')
+        assert torch.equal(E.conv_wgrad(p, x_op, dy_op), red['1'])
+    finally:
+        E.set_precision('fp32')
