@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
 
     TT(0);
     // deferred BatchNorm finalisation: scale / shift of the prologue's BatchNorm from its statistics rows, in LDS (the halo
-    // buffers are free yet: 12 KB of scratch, the constants behind the reduction scratch)
+    // buffers are free yet: 48 KB of scratch, the constants behind the reduction scratch)
     float* kfin = red + 4 * 32 * 3;
     const bool fin = (PRO == SISR_PRO_AFFINE_ACT || PRO == SISR_PRO_RES_AFFINE) && a.fin.stat != nullptr;
     if (fin) bn_finalize_in_kernel(a.fin, reinterpret_cast<double*>(lds), kfin, blockIdx.x == 0);

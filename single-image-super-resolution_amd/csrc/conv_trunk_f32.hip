@@ -98,10 +98,10 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
 
     CFT(0);
     // deferred BatchNorm finalisation: scale / shift of the prologue's BatchNorm from its statistics rows, in LDS (the halo
-    // buffers are free yet: 12 KB of scratch; the constants behind the reduction scratch)
+    // weights region is free yet: 48 KB of scratch; the constants behind the reduction scratch)
     float* kfin = red + 4 * 32 * 3;
     const bool fin = (PRO == SISR_PRO_AFFINE_ACT || PRO == SISR_PRO_RES_AFFINE) && a.fin.stat != nullptr;
-    if (fin) bn_finalize_in_kernel(a.fin, reinterpret_cast<double*>(halo0), kfin, blockIdx.x == 0);
+    if (fin) bn_finalize_in_kernel(a.fin, reinterpret_cast<double*>(lds), kfin, blockIdx.x == 0);      // (scratch: the weights region, filled later)
     // ---- this workgroup's weights into LDS: global rows are contiguous over (s, ci) for one cout, LDS rows over couts.
     // Every wave takes part, from inside its role branch: the producers put the loads of their first two stages in flight
     // before it ---

@@ -321,7 +321,7 @@ __device__ __forceinline__ void stage_operand_tile(const OperandView& o, float* 
 // S = sum n_b (mean_b - K), Q = sum M2_b + n_b (mean_b - K)^2; mean = K + S / N, M2 = Q - S^2 / N), thread = (channel,
 // one of 8 row splits), splits combined through LDS in a fixed order.  Leaves scale / shift in kfin[0..63] / [64..127]
 // (LDS); the `writer` workgroup also stores scale, shift, mean, invstd to k [4][64] and updates the running statistics as
-// sisr_bn_finalize does (norm.hip: momentum, unbiased variance).  scratch: LDS, 8 * 64 * 3 doubles.  Two barriers.
+// sisr_bn_finalize does (norm.hip: momentum, unbiased variance).  scratch: LDS, 32 * 64 * 3 doubles (48 KB).  Three barriers.
 struct BnFinArgs {
     const float *stat, *cnt, *gamma, *beta;
     float *rm, *rv, *k;
@@ -329,27 +329,53 @@ struct BnFinArgs {
     float momentum, eps;
 };
 __device__ __forceinline__ void bn_finalize_in_kernel(const BnFinArgs& f, double* scratch, float* kfin, bool writer) {
-    const int c = threadIdx.x & 63, split = threadIdx.x >> 6;
-    const double K = (double)f.stat[c];
-    double N = 0.0, S = 0.0, Q = 0.0;
+    // thread = (4 consecutive channels c4, one of 32 row splits): 16-byte loads, ~8 rows per thread at 231 rows -- two
+    // memory round trips instead of the eight of a (channel, 8 splits) mapping; the 32 partial sums of a channel are
+    // then added in two fixed-order stages (4 groups of 8 through LDS)
+    const int c4 = threadIdx.x & 15, split32 = threadIdx.x >> 4;
+    const f32x4 K4 = *reinterpret_cast<const f32x4*>(f.stat + 4 * c4);
+    double N4 = 0.0, S4[4] = {0.0, 0.0, 0.0, 0.0}, Q4[4] = {0.0, 0.0, 0.0, 0.0};
 #ifndef BNFIN_UNROLL
 #define BNFIN_UNROLL 4
 #endif
 #pragma unroll BNFIN_UNROLL
-    for (int t = split; t < f.rows; t += 8) {
+    for (int t = split32; t < f.rows; t += 32) {
         const double nb = (double)f.cnt[t];
-        const double dm = (double)f.stat[(int64_t)t * 128 + c] - K;
-        N += nb;
-        S += nb * dm;
-        Q += (double)f.stat[(int64_t)t * 128 + 64 + c] + nb * dm * dm;
+        const f32x4 mb = *reinterpret_cast<const f32x4*>(f.stat + (int64_t)t * 128 + 4 * c4);
+        const f32x4 qb = *reinterpret_cast<const f32x4*>(f.stat + (int64_t)t * 128 + 64 + 4 * c4);
+        N4 += nb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double dm = (double)mb[j] - (double)K4[j];
+            S4[j] += nb * dm;
+            Q4[j] += (double)qb[j] + nb * dm * dm;
+        }
     }
+    // stage 1: LDS [32 splits][64 channels][3]; thread (channel c, group of 8 splits) adds its 8 in order
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double* w = scratch + (split32 * 64 + 4 * c4 + j) * 3;
+        w[0] = N4; w[1] = S4[j]; w[2] = Q4[j];
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 63, split = threadIdx.x >> 6;          // split = group of 8 row splits (0 .. 7; 4 .. 7 idle)
+    const double K = (double)f.stat[c];
+    double N = 0.0, S = 0.0, Q = 0.0;
+    if (split < 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double* r = scratch + ((8 * split + j) * 64 + c) * 3;
+            N += r[0]; S += r[1]; Q += r[2];
+        }
+    }
+    __syncthreads();                                                   // stage-1 rows are consumed: reuse the scratch
     double* my = scratch + (split * 64 + c) * 3;
     my[0] = N; my[1] = S; my[2] = Q;
     __syncthreads();
     if (threadIdx.x < 64) {
         N = 0.0; S = 0.0; Q = 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const double* r = scratch + (j * 64 + c) * 3;
             N += r[0]; S += r[1]; Q += r[2];
         }
