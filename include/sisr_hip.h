@@ -171,6 +171,11 @@ int sisr_conv2d_f32_parts(const SisrConvDesc *d);
  * sisr_conv2d_f32 -- one per workgroup of the persistent fp32 trunk kernel; 0 when that kernel does not take `d` (the
  * generic fp32 kernel has no such epilogue: leave bnb_part NULL and run sisr_bn_bwd's own reduction). */
 int sisr_conv2d_f32_bnb_parts(const SisrConvDesc *d);
+/* bf16 build: the two 9x9 convolutions over a 3-channel NCHW fp32 image that produce 64 bf16 NHWC channels -- the
+ * generator's first conv (model_generator.py:33) and the data gradient of its last one (model_generator.py:52, tanh'
+ * as prologue) -- run on conv_thin.hip (bf16 MFMA operands like every other layer of that build) behind
+ * sisr_conv2d_f32 when H % 16 == W % 16 == 0; tells whether a filled descriptor will. */
+int sisr_conv2d_thin_eligible(const SisrConvDesc *d);
 int sisr_wgrad_plan_bf16(SisrWgradDesc *d, int32_t max_pixel_blocks);
 int sisr_conv2d_wgrad_bf16(const SisrWgradDesc *d, void *stream);
 /* The trunk geometry with bf16 NHWC operands (x prologue NONE / ACT / AFFINE_ACT, gradient prologue BNBWD /

@@ -419,6 +419,8 @@ static int launch_conv(const SisrConvDesc* d, hipStream_t st) {
 
 extern "C" int sisr_conv2d_trunk_f32_eligible(const SisrConvDesc* d);
 int sisr_conv2d_trunk_f32_launch(const SisrConvDesc* d, hipStream_t st);      // conv_trunk_f32.hip
+extern "C" int sisr_conv2d_thin_eligible(const SisrConvDesc* d);
+int sisr_conv2d_thin_launch(const SisrConvDesc* d, hipStream_t st);           // conv_thin.hip
 
 extern "C" int sisr_conv2d_f32(const SisrConvDesc* d, void* stream) {
     // fused BatchNorm-backward partials: bf16 kernels and the persistent fp32 trunk kernel only
@@ -433,6 +435,7 @@ extern "C" int sisr_conv2d_f32(const SisrConvDesc* d, void* stream) {
     if (p.n_tiles <= 0 || p.lds_bytes <= 0 || p.lds_bytes > 160 * 1024) return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (sisr_conv2d_trunk_f32_eligible(d)) return sisr_conv2d_trunk_f32_launch(d, st);
+    if (sisr_conv2d_thin_eligible(d)) return sisr_conv2d_thin_launch(d, st);    // bf16 build: 9x9 over a 3-channel image
     if (d->pro_mode == SISR_PRO_RES_AFFINE) return SISR_E_UNSUPPORTED;      // persistent trunk kernels only
     const bool trunk = d->Cin == 64 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1;
     if (p.msub == 2 && p.nsub == 2) return trunk ? launch_conv<2, 2, 1>(d, st) : launch_conv<2, 2, 0>(d, st);

@@ -824,3 +824,53 @@ def test_trunk_kernel_upscale_conv_weight_gradient(E, L, shape, monkeypatch):
         assert torch.equal(E.conv_wgrad(p, x_op, dy_op), red['1'])
     finally:
         E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('role', ['first_conv', 'end_dgrad'])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 48, 48), (1, 96, 96)])
+def test_thin_kernel_over_a_3_channel_image(E, L, shape, role, monkeypatch):
+    """conv_thin.hip -- the generator's first conv (model_generator.py:32: 9x9, NCHW fp32 image -> 64 bf16 NHWC channels)
+    and the data gradient of its last conv (model_generator.py:52-53: 3x3 over the 3-channel image gradient with tanh'
+    as prologue and the flipped weights) -- against the generic kernel the same descriptor runs on with SISR_THIN=0 and
+    against F.conv2d / autograd on the bf16-rounded operands"""
+    n, h, w = shape
+    monkeypatch.setenv('SISR_STORAGE', 'bf16')
+    bf = lambda t: t.bfloat16().float()
+    E.set_precision('bf16')
+    try:
+        out = {}
+        if role == 'first_conv':
+            x = _rand((n, 3, h, w), 201)
+            wt = _rand((64, 3, 9, 9), 202, (1.0 / 243) ** 0.5 * 1.7)
+            b = _rand((64,), 203, 0.1)
+            y_ref = F.conv2d(bf(x), bf(wt), b, padding=4)
+            ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(3, 64, 9, 1, 4))
+            p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+            op = E.Operand.plain(x.cuda(), dims=(n, h, w, 3), mode=L.X_NCHW)
+            for sw in ('1', '0'):
+                monkeypatch.setenv('SISR_THIN', sw)
+                out[sw] = E.conv_forward(p, op, bias=ref.bias)[0]
+            assert out['1'].dtype == torch.bfloat16 and tuple(out['1'].shape) == (n, h, w, 64)
+            assert maxrel(nchw(out['1'].float()), y_ref) < 8e-3       # (bf16 rounding of the stored result)
+        else:
+            xin = _rand((n, 64, h, w), 211).requires_grad_(True)
+            wt = _rand((3, 64, 3, 3), 212, (1.0 / 576) ** 0.5 * 1.7)
+            yt = torch.tanh(F.conv2d(xin, bf(wt), None, padding=1))
+            g = _rand((n, 3, h, w), 213)
+            gpre = bf(g * (1 - yt.detach() ** 2))                     # what the kernel's staging hands the matrix cores
+            gx_ref, = torch.autograd.grad(F.conv2d(xin, bf(wt), None, padding=1), xin, gpre)
+            ref = FakeConv(wt.cuda(), None, E.ConvGeom(64, 3, 3, 1, 1))
+            p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+            dy = E.Operand(g.cuda(), (n, h, w, 3), pro=L.PRO_TANH_BWD, mode=L.X_NCHW, x2=yt.detach().cuda())
+            for sw in ('1', '0'):
+                monkeypatch.setenv('SISR_THIN', sw)
+                out[sw] = E.conv_dgrad(p, dy)
+            assert out['1'].dtype == torch.bfloat16 and tuple(out['1'].shape) == (n, h, w, 64)
+            assert maxrel(nchw(out['1'].float()), gx_ref) < 8e-3
+        # same descriptor on the generic kernel (bf16 multiplicands there as well; fp32-accumulation order differs)
+        assert maxrel(out['1'].float(), out['0'].float()) < 1.2e-2
+        monkeypatch.setenv('SISR_THIN', '1')
+        again = E.conv_forward(p, op, bias=ref.bias)[0] if role == 'first_conv' else E.conv_dgrad(p, dy)
+        assert torch.equal(again, out['1'])
+    finally:
+        E.set_precision('fp32')
