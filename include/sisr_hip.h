@@ -188,6 +188,10 @@ int sisr_wgrad_bf16_slabs(const SisrWgradDesc *d);
  * persistent exact-fp32 kernel of wgrad_trunk_f32.hip behind sisr_conv2d_wgrad_f32 (one slab per workgroup). */
 int sisr_wgrad_trunk_f32_eligible(const SisrWgradDesc *d);
 int sisr_wgrad_f32_slabs(const SisrWgradDesc *d);
+/* bf16 build: the weight gradient of the generator's first conv (9x9 over the 3-channel NCHW fp32 image, bf16 NHWC
+ * output gradient with no / activation-backward prologue, H % 8 == 0, W % 32 == 0) runs on wgrad_thin.hip (bf16 MFMA)
+ * behind sisr_conv2d_wgrad_f32; tells whether a filled descriptor will (sisr_wgrad_f32_slabs accounts for it). */
+int sisr_wgrad_thin_eligible(const SisrWgradDesc *d);
 int sisr_conv2d_wgrad_f32(const SisrWgradDesc *d, void *stream);
 /* out[i] = sum_s slab[s][i], i < elems (also used for the bias slabs) */
 int sisr_slab_reduce_f32(const float *slab, float *out, int32_t n_slabs, int64_t elems, void *stream);

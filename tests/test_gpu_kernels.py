@@ -874,3 +874,49 @@ def test_thin_kernel_over_a_3_channel_image(E, L, shape, role, monkeypatch):
         assert torch.equal(again, out['1'])
     finally:
         E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('act', [True, False])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 64), (1, 96, 96)])
+def test_thin_kernel_first_conv_weight_gradient(E, L, shape, act, monkeypatch):
+    """wgrad_thin.hip -- weight / bias gradient of the generator's first conv (model_generator.py:32-33: 9x9 over the
+    NCHW fp32 image; the gradient arrives through the PReLU, activation-backward prologue) -- against the generic
+    exact-fp32 kernel the same descriptor runs on with SISR_THIN=0 and against autograd"""
+    n, h, w = shape
+    monkeypatch.setenv('SISR_STORAGE', 'bf16')
+    bf = lambda t: t.bfloat16().float()
+    x = _rand((n, 3, h, w), 221)
+    wt = _rand((64, 3, 9, 9), 222, (1.0 / 243) ** 0.5 * 1.7)
+    b = _rand((64,), 223, 0.1)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pre_ref = F.conv2d(bf(x), wr, br, padding=4)               # (the kernel multiplies bf16-rounded image values)
+    pre = bf(pre_ref.detach())                                  # the stored pre-activation (bf16 NHWC in the engine)
+    g = bf(_rand((n, 64, h, w), 224))
+    gpre = bf(torch.where(pre > 0, g, 0.25 * g)) if act else g
+    pre_ref.backward(gpre)
+    E.set_precision('bf16')
+    try:
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(3, 64, 9, 1, 4))
+        p = E.prepare_weights([(ref, n, h, w)], training=True, need_dgrad=False)[0][0]
+        x_op = E.Operand.plain(x.cuda(), dims=(n, h, w, 3), mode=L.X_NCHW)
+        gd, pd_ = nhwc(g).cuda().bfloat16(), nhwc(pre).cuda().bfloat16()
+        slope = torch.tensor([0.25], device='cuda')
+        dy_op = E.Operand(gd, (n, h, w, 64), pro=L.PRO_ACT_BWD, x2=pd_, slope=slope) if act else E.Operand.plain(gd)
+        red = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_THIN', sw)
+            red[sw] = E.conv_wgrad(p, x_op, dy_op)
+        assert red['1'].shape == red['0'].shape == (9 * 28 * 64 + 64,)
+        # packed layout [ky][kx * 3 + ci, padded 27 -> 28][co] + bias row; the padding row is not part of the gradient
+        # (this kernel writes zeros there, the generic one leaves it as allocated)
+        body = lambda r: torch.cat([r[:9 * 28 * 64].view(9, 28, 64)[:, :27].reshape(-1), r[9 * 28 * 64:]])
+        assert maxrel(body(red['1']), body(red['0'])) < 8e-3     # (fp32 image values / unrounded act' there)
+        assert float(red['1'][:9 * 28 * 64].view(9, 28, 64)[:, 27].abs().max()) == 0.0
+        wg = E.WeightGradBatch()
+        wg.add(p, red['1'])
+        gw, gb = wg.run()[id(ref)]
+        assert maxrel(gw, wr.grad) < 2e-3 and maxrel(gb, br.grad) < 2e-3
+        monkeypatch.setenv('SISR_THIN', '1')
+        assert torch.equal(E.conv_wgrad(p, x_op, dy_op), red['1'])
+    finally:
+        E.set_precision('fp32')
