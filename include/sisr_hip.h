@@ -176,6 +176,10 @@ int sisr_conv2d_f32_bnb_parts(const SisrConvDesc *d);
  * as prologue) -- run on conv_thin.hip (bf16 MFMA operands like every other layer of that build) behind
  * sisr_conv2d_f32 when H % 16 == W % 16 == 0; tells whether a filled descriptor will. */
 int sisr_conv2d_thin_eligible(const SisrConvDesc *d);
+/* bf16 build: the generator's last conv (model_generator.py:52-53: 3x3, 64 -> 3, bf16 NHWC in, NCHW fp32 out, prologue
+ * NONE / ACT, epilogue NONE / TANH) runs on conv_toimage.hip (1x1 GEMM onto 27 (cout, tap) columns + col2im gather)
+ * behind sisr_conv2d_bf16; tells whether a filled descriptor will. */
+int sisr_conv2d_toimage_eligible(const SisrConvDesc *d);
 int sisr_wgrad_plan_bf16(SisrWgradDesc *d, int32_t max_pixel_blocks);
 int sisr_conv2d_wgrad_bf16(const SisrWgradDesc *d, void *stream);
 /* The trunk geometry with bf16 NHWC operands (x prologue NONE / ACT / AFFINE_ACT, gradient prologue BNBWD /

@@ -646,6 +646,8 @@ static int launch_conv_bf16(const SisrConvDesc* d, hipStream_t st) {
 
 extern "C" int sisr_conv2d_trunk_eligible(const SisrConvDesc* d);
 int sisr_conv2d_trunk_launch(const SisrConvDesc* d, hipStream_t st);            // conv_trunk.hip
+extern "C" int sisr_conv2d_toimage_eligible(const SisrConvDesc* d);
+int sisr_conv2d_toimage_launch(const SisrConvDesc* d, hipStream_t st);          // conv_toimage.hip
 
 extern "C" int sisr_conv2d_bf16(const SisrConvDesc* d, void* stream) {
     if (!d || !d->x1 || !d->wpk || !d->y) return SISR_E_BADARG;
@@ -666,6 +668,7 @@ extern "C" int sisr_conv2d_bf16(const SisrConvDesc* d, void* stream) {
     if (p.CK != BF_CK || p.PS != BF_PS || p.n_tiles <= 0 || p.lds_bytes <= 0 || p.lds_bytes > 160 * 1024)
         return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (sisr_conv2d_toimage_eligible(d)) return sisr_conv2d_toimage_launch(d, st);      // the generator's last conv (64 -> 3)
     if (sisr_conv2d_trunk_eligible(d)) {                // the generator's trunk geometry: persistent weights-in-registers kernel
         if (d->stat_part && !d->cnt_part) return SISR_E_BADARG;
         return sisr_conv2d_trunk_launch(d, st);

@@ -920,3 +920,38 @@ def test_thin_kernel_first_conv_weight_gradient(E, L, shape, act, monkeypatch):
         assert torch.equal(E.conv_wgrad(p, x_op, dy_op), red['1'])
     finally:
         E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('pro,tanh', [('act', True), ('none', True), ('act', False)])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 13, 31), (1, 96, 96), (2, 192, 192)])
+def test_last_conv_as_gemm_plus_col2im(E, L, shape, pro, tanh, monkeypatch):
+    """conv_toimage.hip -- the generator's last conv (model_generator.py:52-53: 3x3, 64 -> 3, + Tanh; bf16 NHWC
+    activations in, NCHW fp32 image out; PReLU of the upscale stage as prologue) -- against the generic bf16 kernel the
+    same descriptor runs on with SISR_THIN=0 and against F.conv2d on the bf16-rounded operands; ragged sizes included"""
+    n, h, w = shape
+    monkeypatch.setenv('SISR_STORAGE', 'bf16')
+    bf = lambda t: t.bfloat16().float()
+    x = bf(_rand((n, 64, h, w), 231) * 2.0)
+    wt = _rand((3, 64, 3, 3), 232, (1.0 / 576) ** 0.5 * 1.7)
+    b = _rand((3,), 233, 0.1)
+    xin = bf(F.leaky_relu(x, 0.25)) if pro == 'act' else x
+    y_ref = F.conv2d(xin, bf(wt), b, padding=1)
+    y_ref = torch.tanh(y_ref) if tanh else y_ref
+    E.set_precision('bf16')
+    try:
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 3, 3, 1, 1))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        xd = nhwc(x).cuda().bfloat16()
+        op = E.Operand.plain(xd) if pro == 'none' else E.Operand.act(xd, torch.tensor([0.25], device='cuda'))
+        out = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_THIN', sw)
+            out[sw] = E.conv_forward(p, op, bias=ref.bias, y_mode=L.Y_NCHW, epi=L.EPI_TANH if tanh else L.EPI_NONE)[0]
+        assert out['1'].dtype == torch.float32 and tuple(out['1'].shape) == (n, 3, h, w)
+        assert maxrel(out['1'], y_ref) < 2e-3
+        assert maxrel(out['1'], out['0']) < 2e-3
+        monkeypatch.setenv('SISR_THIN', '1')
+        again = E.conv_forward(p, op, bias=ref.bias, y_mode=L.Y_NCHW, epi=L.EPI_TANH if tanh else L.EPI_NONE)[0]
+        assert torch.equal(again, out['1'])
+    finally:
+        E.set_precision('fp32')
