@@ -196,6 +196,11 @@ int sisr_wgrad_f32_slabs(const SisrWgradDesc *d);
  * output gradient with no / activation-backward prologue, H % 8 == 0, W % 32 == 0) runs on wgrad_thin.hip (bf16 MFMA)
  * behind sisr_conv2d_wgrad_f32; tells whether a filled descriptor will (sisr_wgrad_f32_slabs accounts for it). */
 int sisr_wgrad_thin_eligible(const SisrWgradDesc *d);
+/* bf16 build: the weight gradient of the generator's last conv (3x3, 64 -> 3; bf16 NHWC x with prologue NONE / ACT, the
+ * NCHW fp32 image gradient itself -- prologue NONE / TANH_BWD -- as g1 / g2, H % 8 == 0, W % 32 == 0, descriptor planned
+ * by sisr_wgrad_plan_bf16 for the gradient padded to 4 channels) runs on wgrad_toimage.hip behind sisr_conv2d_wgrad_bf16:
+ * no 4-channel NHWC copy of the gradient is needed then; same slab layout (sisr_wgrad_bf16_slabs accounts for it). */
+int sisr_wgrad_toimage_eligible(const SisrWgradDesc *d);
 int sisr_conv2d_wgrad_f32(const SisrWgradDesc *d, void *stream);
 /* out[i] = sum_s slab[s][i], i < elems (also used for the bias slabs) */
 int sisr_slab_reduce_f32(const float *slab, float *out, int32_t n_slabs, int64_t elems, void *stream);

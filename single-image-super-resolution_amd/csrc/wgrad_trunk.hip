@@ -388,9 +388,13 @@ extern "C" int sisr_wgrad_trunk_eligible(const SisrWgradDesc* d) {
 }
 
 // slabs a launch of this descriptor writes (rows of `slab` at slab_stride): one per workgroup
+extern "C" int sisr_wgrad_toimage_eligible(const SisrWgradDesc* d);
+int sisr_wgrad_toimage_slabs(const SisrWgradDesc* d);                         // wgrad_toimage.hip
+
 extern "C" int sisr_wgrad_bf16_slabs(const SisrWgradDesc* d) {
     if (!d) return SISR_E_BADARG;
-    return sisr_wgrad_trunk_eligible(d) ? wtrunk_grid(d) / (d->Cout == 256 ? 4 : 1) : d->n_slabs;
+    if (sisr_wgrad_trunk_eligible(d)) return wtrunk_grid(d) / (d->Cout == 256 ? 4 : 1);
+    return sisr_wgrad_toimage_eligible(d) ? sisr_wgrad_toimage_slabs(d) : d->n_slabs;
 }
 
 template <int GPRO>

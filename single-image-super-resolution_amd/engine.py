@@ -501,7 +501,13 @@ def conv_wgrad(prep, x_op, dy_op):
     assert tuple(x_op.dims) == (g.N, g.H, g.W, g.Cin) and tuple(dy_op.dims) == (g.N, g.Ho, g.Wo, cout), \
         (x_op.dims, dy_op.dims)
     dev = x_op.x1.device
-    if g.Cout != cout:          # bf16 kernel on a channel-padded NHWC copy of the (NCHW, few-channel) gradient
+    direct = False
+    if g.Cout != cout and dy_op.mode == L.X_NCHW:
+        # the generator's last conv (64 -> 3) has a kernel that reads the NCHW image gradient itself (wgrad_toimage.hip)
+        x_op.fill(g)
+        dy_op.fill(g, g=True)
+        direct = bool(lib.sisr_wgrad_toimage_eligible(C.byref(g)))
+    if g.Cout != cout and not direct:   # bf16 kernel on a channel-padded NHWC copy of the (NCHW, few-channel) gradient
         if dy_op.mode != L.X_NCHW or dy_op.pro not in (L.PRO_NONE, L.PRO_TANH_BWD):
             raise RuntimeError('padded weight gradient: NCHW gradient with no / tanh-backward prologue expected')
         g4 = torch.empty((g.N, g.Ho, g.Wo, g.Cout), dtype=torch.float32, device=dev)

@@ -955,3 +955,50 @@ def test_last_conv_as_gemm_plus_col2im(E, L, shape, pro, tanh, monkeypatch):
         assert torch.equal(again, out['1'])
     finally:
         E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('pro,tanh', [('act', True), ('none', False)])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 64), (1, 96, 96)])
+def test_last_conv_weight_gradient_reads_the_image_gradient_directly(E, L, shape, pro, tanh, monkeypatch):
+    """wgrad_toimage.hip -- weight / bias gradient of the generator's last conv (model_generator.py:52-53: 3x3, 64 -> 3,
+    + Tanh; bf16 NHWC activations through the PReLU prologue, NCHW fp32 image gradient through tanh') -- against the
+    generic bf16 kernel (which runs on a 4-channel NHWC copy of the gradient, SISR_THIN=0) and against autograd"""
+    n, h, w = shape
+    monkeypatch.setenv('SISR_STORAGE', 'bf16')
+    bf = lambda t: t.bfloat16().float()
+    x = bf(_rand((n, 64, h, w), 241) * 2.0)
+    wt = _rand((3, 64, 3, 3), 242, (1.0 / 576) ** 0.5 * 1.7)
+    b = _rand((3,), 243, 0.1)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xin = bf(F.leaky_relu(x, 0.25)) if pro == 'act' else x
+    pre = F.conv2d(xin, wr, br, padding=1)
+    y = torch.tanh(pre) if tanh else pre
+    g = _rand((n, 3, h, w), 244)
+    gpre = bf(g * (1 - y.detach() ** 2)) if tanh else bf(g)       # what the staging hands the matrix cores
+    pre.backward(gpre)
+    E.set_precision('bf16')
+    try:
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 3, 3, 1, 1))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        xd = nhwc(x).cuda().bfloat16()
+        x_op = E.Operand.plain(xd) if pro == 'none' else E.Operand.act(xd, torch.tensor([0.25], device='cuda'))
+        if tanh:
+            dy_op = E.Operand(g.cuda(), (n, h, w, 3), pro=L.PRO_TANH_BWD, mode=L.X_NCHW, x2=y.detach().cuda())
+        else:
+            dy_op = E.Operand.plain(g.cuda(), dims=(n, h, w, 3), mode=L.X_NCHW)
+        red = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_THIN', sw)
+            red[sw] = E.conv_wgrad(p, x_op, dy_op)
+        assert red['1'].shape == red['0'].shape
+        assert maxrel(red['1'], red['0']) < 2e-3
+        wg = E.WeightGradBatch()
+        wg.add(p, red['1'])
+        gw, gb = wg.run()[id(ref)]
+        # (the bias gradient is summed in fp32 from the unrounded tanh' products, the matrix operand is their bf16 rounding)
+        gb_ref = (g * (1 - y.detach() ** 2) if tanh else g).sum(dim=(0, 2, 3))
+        assert maxrel(gw, wr.grad) < 2e-3 and maxrel(gb, gb_ref) < 1e-4
+        monkeypatch.setenv('SISR_THIN', '1')
+        assert torch.equal(E.conv_wgrad(p, x_op, dy_op), red['1'])
+    finally:
+        E.set_precision('fp32')
