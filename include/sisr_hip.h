@@ -258,6 +258,8 @@ typedef struct SisrWeightGradDesc {
 
 /* parts = the largest tile count of the table, tiles of a weight = ceil(Cout/32) * ceil(Cin/C) with C = 32 for
  * layout 1 (bf16 slabs) and CK otherwise; dot_work: >= parts*n floats of scratch */
+/* workgroups along grid.y (= dot_work entries) one weight needs; `parts` >= the maximum over the table (host only) */
+int sisr_weights_grad_tiles(const SisrWeightGradDesc *w);
 int sisr_weights_grad(const SisrWeightGradDesc *table_dev, int32_t n, float *dot_work, int32_t parts, void *stream);
 
 /* ---- BatchNorm2d (training) pieces that are not fused into the convolutions ------------------

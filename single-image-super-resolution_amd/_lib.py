@@ -117,6 +117,7 @@ _SIGS = {
     'sisr_slab_reduce_f32': [_f, _f, _i32, _i64, _f],
     'sisr_weights_prepare': [_f, _i32, _i32, _i32, _f],
     'sisr_weights_grad': [_f, _i32, _f, _i32, _f],
+    'sisr_weights_grad_tiles': [C.POINTER(WeightGradDesc)],
     'sisr_bn_finalize': [_f, _f, _i32, _i32, _f, _f, _f, _f, _f32, _f32, _f, _f, _f, _f, _f],
     'sisr_bn_eval_consts': [_f, _f, _f, _f, _f32, _i32, _f, _f, _f],
     'sisr_bn_bwd_plan': [C.POINTER(BnBwdDesc)],
@@ -191,3 +192,10 @@ def lib():
 def check(status, what):
     if status != 0:
         raise RuntimeError('%s failed with status %d' % (what, status))
+
+
+def check_count(value, what):
+    """entry points that answer a sizing question return a count >= 0 or a negative status"""
+    if value < 0:
+        raise RuntimeError('%s failed with status %d' % (what, value))
+    return value

@@ -264,24 +264,37 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
 // couts, contiguous writes along (ci, r, s).  Two launches over grid (weights, max tiles per weight):
 //   1. partial <G, W_orig> per tile  -> dot_part[w][tile]   (deterministic order)
 //   2. every tile sums the partials of its weight and writes its share of the OIHW gradient
-#define WGT_ROWS 324                                     // LDS rows per pass (taps x channels of the chunk)
-__device__ __forceinline__ int wgt_tiles(const SisrWeightGradDesc& w) {
+#define WGT_ROWS 64                                      // LDS rows per tile (taps x channels of the chunk, wgt_tg)
+// A weight's un-packing is cut into tiles of 32 packed couts x one channel chunk x a GROUP OF TAPS of ~32 LDS rows, one
+// workgroup each: a trunk layer (64 x 64 x 9) is 36 tiles with one memory round trip per phase (it was 4 tiles walking 9
+// dependent rounds each: 26-30 us for the 37 layers of the generator, latency-bound with 150 busy workgroups).
+__host__ __device__ __forceinline__ int wgt_tg(const SisrWeightGradDesc& w) {      // taps per tile
+    const int ck = w.layout == 1 ? 32 : w.CK, nci = ck < w.Cin ? ck : w.Cin, taps = w.KH * w.KW;
+    const int tg = nci > 0 ? 32 / nci : 1;
+    return tg < 1 ? 1 : (tg > taps ? taps : tg);
+}
+__host__ __device__ __forceinline__ int wgt_base_tiles(const SisrWeightGradDesc& w) {
     const int ck = w.layout == 1 ? 32 : w.CK;
     return ((w.Cout + 31) / 32) * ((w.Cin + ck - 1) / ck);
+}
+__host__ __device__ __forceinline__ int wgt_tiles(const SisrWeightGradDesc& w) {
+    const int tg = wgt_tg(w);
+    return wgt_base_tiles(w) * ((w.KH * w.KW + tg - 1) / tg);
 }
 
 // mode 0: returns this thread's share of <G, W_orig> over the tile; mode 1: writes the gradient
 template <int MODE>
 __device__ __forceinline__ float wgt_tile(const SisrWeightGradDesc& w, int tile, float* lds, float gw, float inv) {
     const int tid = threadIdx.x;
-    const int n_cot = (w.Cout + 31) / 32;
-    const int cot = tile % n_cot, chunk = tile / n_cot;
+    const int n_cot = (w.Cout + 31) / 32, n_base = wgt_base_tiles(w);
+    const int base = tile % n_base, tgi = tile / n_base;
+    const int cot = base % n_cot, chunk = base / n_cot;
     const int ck = w.layout == 1 ? 32 : w.CK;
     const int ci0 = chunk * ck, nci = min(ck, w.Cin - ci0);
     const int taps = w.KH * w.KW, cols = w.Cin * taps, Cq = w.Cout >> 2;
-    const int tgroup = max(1, min(taps, WGT_ROWS / nci));           // taps per LDS pass
+    const int tgroup = wgt_tg(w);                                   // taps of this tile (rows = taps x channels <= WGT_ROWS)
     float part = 0.f;
-    for (int t0 = 0; t0 < taps; t0 += tgroup) {
+    for (int t0 = tgi * tgroup; t0 < min(taps, (tgi + 1) * tgroup); t0 += tgroup) {
         const int nt = min(tgroup, taps - t0), rows = nt * nci;
         __syncthreads();
         // 4 independent 128-byte-coalesced loads in flight per thread before the LDS stores (the tile is otherwise
@@ -396,6 +409,13 @@ extern "C" int sisr_weights_prepare(const SisrWeightDesc* table_dev, int32_t n, 
     hipLaunchKernelGGL(weights_pack_kernel, dim3(n, parts_for(2ll * max_rows * max_cols)), dim3(SISR_BLOCK), 0, st, table_dev);
     SISR_CHECK_LAUNCH();
     return 0;
+}
+
+// tiles (= workgroups along grid.y, = dot_work entries) one weight of the table needs; `parts` of sisr_weights_grad must
+// be >= the maximum over the table
+extern "C" int sisr_weights_grad_tiles(const SisrWeightGradDesc* w) {
+    if (!w || w->Cout <= 0 || w->Cin <= 0 || w->KH <= 0 || w->KW <= 0 || (w->layout != 1 && w->CK <= 0)) return SISR_E_BADARG;
+    return wgt_tiles(*w);
 }
 
 extern "C" int sisr_weights_grad(const SisrWeightGradDesc* table_dev, int32_t n, float* dot_work, int32_t parts,

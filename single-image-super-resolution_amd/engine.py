@@ -564,10 +564,7 @@ class WeightGradBatch:
             t.layout = 1 if p.kinds[2] else 0
             res[id(p.ref)] = (gw, gb)
         tab = _table_to_device(table, dev)
-        def tiles(t):                      # tiles of one weight: 32 packed couts x one channel chunk
-            ck = 32 if t.layout == 1 else t.CK
-            return ((t.Cout + 31) // 32) * ((t.Cin + ck - 1) // ck)
-        parts = max(tiles(t) for t in table)
+        parts = max(L.check_count(lib.sisr_weights_grad_tiles(C.byref(t)), 'sisr_weights_grad_tiles') for t in table)
         work = torch.empty((parts * len(self.items),), dtype=torch.float32, device=dev)
         L.check(lib.sisr_weights_grad(tab.data_ptr(), len(self.items), work.data_ptr(), parts, _stream()),
                 'sisr_weights_grad')
