@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
         // [chunk][r][cp][krow], krow = s*PS + (ci - chunk*CK)
         const int64_t total = (int64_t)w.f_n_chunk * w.KH * w.f_CoutPad * w.f_KROWP;
         for (int64_t e = start; e < total; e += stride) {
-            int64_t tq = e;
+            unsigned tq = (unsigned)e;          // (packed images are far below 2^32 elements: 32-bit index arithmetic)
             const int krow = (int)(tq % w.f_KROWP); tq /= w.f_KROWP;
             const int cp = (int)(tq % w.f_CoutPad); tq /= w.f_CoutPad;
             const int r = (int)(tq % w.KH);
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
         // Wd[op = ci][ip = cp][r'][s'] = W[co(cp)][ci][KH-1-r'][KW-1-s']
         const int64_t total = (int64_t)w.d_n_chunk * w.KH * w.d_CoutPad * w.d_KROWP;
         for (int64_t e = start; e < total; e += stride) {
-            int64_t tq = e;
+            unsigned tq = (unsigned)e;
             const int krow = (int)(tq % w.d_KROWP); tq /= w.d_KROWP;
             const int op = (int)(tq % w.d_CoutPad); tq /= w.d_CoutPad;
             const int r = (int)(tq % w.KH);
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
         const int taps = w.KH * w.KW, WSG = taps * CKb;
         const int64_t total = (int64_t)(w.Cin / CKb) * w.bf_f_CoutPad * WSG;
         for (int64_t e = start; e < total; e += stride) {
-            int64_t tq = e;
+            unsigned tq = (unsigned)e;
             const int kidx = (int)(tq % WSG); tq /= WSG;
             const int cp = (int)(tq % w.bf_f_CoutPad);
             const int chunk = (int)(tq / w.bf_f_CoutPad);
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
         const int taps = w.KH * w.KW, WSG = taps * CKb;
         const int64_t total = (int64_t)(w.Cout / CKb) * w.bf_d_CoutPad * WSG;
         for (int64_t e = start; e < total; e += stride) {
-            int64_t tq = e;
+            unsigned tq = (unsigned)e;
             const int kidx = (int)(tq % WSG); tq /= WSG;
             const int op = (int)(tq % w.bf_d_CoutPad);
             const int chunk = (int)(tq / w.bf_d_CoutPad);
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
         const int KHc = w.c_KH[cls], KWc = w.c_KW[cls], WSG = KHc * KWc * 32, CoutPad = w.bf_c_CoutPad[cls];
         const int64_t total = (int64_t)(w.Cout / 32) * CoutPad * WSG;
         for (int64_t e = start; e < total; e += stride) {
-            int64_t tq = e;
+            unsigned tq = (unsigned)e;
             const int kidx = (int)(tq % WSG); tq /= WSG;
             const int op = (int)(tq % CoutPad);
             const int chunk = (int)(tq / CoutPad);
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
         const int CK = w.c_CK[cls], PS = w.c_PS[cls], KROWP = w.c_KROWP[cls], CoutPad = w.c_CoutPad[cls];
         const int64_t total = (int64_t)w.c_n_chunk[cls] * KHc * CoutPad * KROWP;
         for (int64_t e = start; e < total; e += stride) {
-            int64_t tq = e;
+            unsigned tq = (unsigned)e;
             const int krow = (int)(tq % KROWP); tq /= KROWP;
             const int op = (int)(tq % CoutPad); tq /= CoutPad;
             const int rp = (int)(tq % KHc);
@@ -367,6 +367,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_grad_dot_kernel(const Sisr
 
 __global__ void __launch_bounds__(SISR_BLOCK) weights_grad_kernel(const SisrWeightGradDesc* table, const float* dot_part) {
     __shared__ float lds[WGT_ROWS * 33];
+    __shared__ float scratch[8];
     const SisrWeightGradDesc w = table[blockIdx.x];
     const int tid = threadIdx.x, n_tiles = wgt_tiles(w);
     if ((int)blockIdx.y >= n_tiles) return;
@@ -379,8 +380,11 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_grad_kernel(const SisrWeig
     float gw = 0.f, inv = 1.f;
     if (w.u_used != nullptr) {
         const float sigma = w.sigma[0];
+        // (a large layer has thousands of tiles: the partial dots are summed by the workgroup, fixed partition and order,
+        // not by every thread on its own)
         float dot = 0.f;
-        for (int k = 0; k < n_tiles; ++k) dot += dot_part[(int64_t)blockIdx.x * gridDim.y + k];
+        for (int k = tid; k < n_tiles; k += SISR_BLOCK) dot += dot_part[(int64_t)blockIdx.x * gridDim.y + k];
+        dot = block_sum(dot, scratch);
         gw = dot / sigma;          // <G, W> with W = W_orig / sigma
         inv = 1.f / sigma;
     }
