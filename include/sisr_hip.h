@@ -180,6 +180,8 @@ int sisr_conv2d_thin_eligible(const SisrConvDesc *d);
  * NONE / ACT, epilogue NONE / TANH) runs on conv_toimage.hip (1x1 GEMM onto 27 (cout, tap) columns + col2im gather)
  * behind sisr_conv2d_bf16; tells whether a filled descriptor will. */
 int sisr_conv2d_toimage_eligible(const SisrConvDesc *d);
+/* ... and with fp32 NHWC tensors (fp32 parity build; exact fp32 MFMA) behind sisr_conv2d_f32 */
+int sisr_conv2d_toimage_f32_eligible(const SisrConvDesc *d);
 int sisr_wgrad_plan_bf16(SisrWgradDesc *d, int32_t max_pixel_blocks);
 int sisr_conv2d_wgrad_bf16(const SisrWgradDesc *d, void *stream);
 /* The trunk geometry with bf16 NHWC operands (x prologue NONE / ACT / AFFINE_ACT, gradient prologue BNBWD /

@@ -105,6 +105,7 @@ _SIGS = {
     'sisr_conv2d_f32_bnb_parts': [C.POINTER(ConvDesc)],
     'sisr_conv2d_thin_eligible': [C.POINTER(ConvDesc)],
     'sisr_conv2d_toimage_eligible': [C.POINTER(ConvDesc)],
+    'sisr_conv2d_toimage_f32_eligible': [C.POINTER(ConvDesc)],
     'sisr_wgrad_trunk_eligible': [C.POINTER(WgradDesc)],
     'sisr_wgrad_bf16_slabs': [C.POINTER(WgradDesc)],
     'sisr_wgrad_trunk_f32_eligible': [C.POINTER(WgradDesc)],

@@ -421,6 +421,8 @@ extern "C" int sisr_conv2d_trunk_f32_eligible(const SisrConvDesc* d);
 int sisr_conv2d_trunk_f32_launch(const SisrConvDesc* d, hipStream_t st);      // conv_trunk_f32.hip
 extern "C" int sisr_conv2d_thin_eligible(const SisrConvDesc* d);
 int sisr_conv2d_thin_launch(const SisrConvDesc* d, hipStream_t st);           // conv_thin.hip
+extern "C" int sisr_conv2d_toimage_f32_eligible(const SisrConvDesc* d);
+int sisr_conv2d_toimage_launch(const SisrConvDesc* d, hipStream_t st);        // conv_toimage.hip
 
 extern "C" int sisr_conv2d_f32(const SisrConvDesc* d, void* stream) {
     // fused BatchNorm-backward partials: bf16 kernels and the persistent fp32 trunk kernel only
@@ -436,6 +438,7 @@ extern "C" int sisr_conv2d_f32(const SisrConvDesc* d, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (sisr_conv2d_trunk_f32_eligible(d)) return sisr_conv2d_trunk_f32_launch(d, st);
     if (sisr_conv2d_thin_eligible(d)) return sisr_conv2d_thin_launch(d, st);    // bf16 build: 9x9 over a 3-channel image
+    if (sisr_conv2d_toimage_f32_eligible(d)) return sisr_conv2d_toimage_launch(d, st);     // the generator's last conv (64 -> 3)
     if (d->pro_mode == SISR_PRO_RES_AFFINE) return SISR_E_UNSUPPORTED;      // persistent trunk kernels only
     const bool trunk = d->Cin == 64 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1;
     if (p.msub == 2 && p.nsub == 2) return trunk ? launch_conv<2, 2, 1>(d, st) : launch_conv<2, 2, 0>(d, st);

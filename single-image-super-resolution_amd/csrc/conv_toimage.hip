@@ -34,8 +34,25 @@ struct ToImageArgs {
     float* y;
     float slope;
     int N, H, W, CoutPad, tanh_epi;
+    int CK, PS, KROWP;                // fp32 variant: layout of the packed fp32 weight image
     int tiles_x, tiles_y;
 };
+
+// col2im gather of the 14 x 30 interior of a region, x fastest (coalesced NCHW stores)
+__device__ __forceinline__ void toimage_gather(const ToImageArgs& a, const float* P, int n, int ty, int tx) {
+    for (int idx = threadIdx.x; idx < 3 * TO_OH * TO_OW; idx += 256) {
+        const int co = idx / (TO_OH * TO_OW), rem = idx - co * (TO_OH * TO_OW), oy = rem / TO_OW, ox = rem - oy * TO_OW;
+        const int Y = ty * TO_OH + oy, Xo = tx * TO_OW + ox;
+        float s = a.bias != nullptr ? a.bias[co] : 0.f;
+        const float* p0 = P + (oy * TO_RW + ox) * TO_PSTR + co * 9;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) s += p0[(ky * TO_RW + kx) * TO_PSTR + ky * 3 + kx];
+        if (a.tanh_epi) s = tanhf(s);
+        if (Y < a.H && Xo < a.W) a.y[((long long)(n * 3 + co) * a.H + Y) * a.W + Xo] = s;
+    }
+}
 
 template <bool ACT>
 __global__ void __launch_bounds__(256, 2) conv_toimage_kernel(const ToImageArgs a) {
@@ -92,31 +109,86 @@ __global__ void __launch_bounds__(256, 2) conv_toimage_kernel(const ToImageArgs 
             if (q < 3 || kk == 0) *reinterpret_cast<f32x4*>(pp + 8 * q) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
     }
     __syncthreads();
-    // ---- col2im gather of the 14 x 30 interior, x fastest (coalesced NCHW stores) -------------------------------------
-    for (int idx = tid; idx < 3 * TO_OH * TO_OW; idx += 256) {
-        const int co = idx / (TO_OH * TO_OW), rem = idx - co * (TO_OH * TO_OW), oy = rem / TO_OW, ox = rem - oy * TO_OW;
-        const int Y = ty * TO_OH + oy, Xo = tx * TO_OW + ox;
-        float s = a.bias != nullptr ? a.bias[co] : 0.f;
-        const float* p0 = P + (oy * TO_RW + ox) * TO_PSTR + co * 9;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) s += p0[(ky * TO_RW + kx) * TO_PSTR + ky * 3 + kx];
-        if (a.tanh_epi) s = tanhf(s);
-        if (Y < a.H && Xo < a.W) a.y[((long long)(n * 3 + co) * a.H + Y) * a.W + Xo] = s;
-    }
+    toimage_gather(a, P, n, ty, tx);
 }
 
-extern "C" int sisr_conv2d_toimage_eligible(const SisrConvDesc* d) {
-    const char* sw = getenv("SISR_THIN");                       // A/B switch: SISR_THIN=0 keeps the generic kernel
+// ---- the same layer with fp32 tensors (fp32 parity build): exact v_mfma_f32_32x32x2_f32, K = 64 channels in 32 steps.
+// The generic fp32 kernel pads the 3 couts to 32 MFMA columns over K = 9 x 64: 255 us; here 2.4 GFLOP and 151 MB.
+// K order: step (j, i) pairs channel 8j + i (lanes 0-31) with channel 8j + 4 + i (lanes 32-63), so that a lane's 32
+// operand values are eight 16-byte loads of its pixel; the weight fragments use the same pairing.
+template <bool ACT>
+__global__ void __launch_bounds__(256, 2) conv_toimage_f32_kernel(const ToImageArgs a) {
+    __shared__ __attribute__((aligned(16))) float P[TO_RH * TO_RW * TO_PSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kk = lane >> 5;
+    const int tx = blockIdx.x % a.tiles_x, t2 = blockIdx.x / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
+    const float slope = a.slope_p ? a.slope_p[0] : a.slope;
+    // A fragments from the packed fp32 image [chunk][ky][cout][kx * PS + cl]
+    float wa[8][4];
+    {
+        const int co = l31 / 9, tap = l31 - 9 * co, ky = tap / 3, kx = tap - 3 * ky;
+        const float* wp = reinterpret_cast<const float*>(a.wpk);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ci = 8 * j + 4 * kk + i, chunk = ci / a.CK, cl = ci - chunk * a.CK;
+                wa[j][i] = l31 < 27 ? wp[((chunk * 3 + ky) * a.CoutPad + co) * a.KROWP + kx * a.PS + cl] : 0.f;
+            }
+    }
+    const __amdgpu_buffer_rsrc_t rx = sisr_rsrc(a.x, (unsigned)a.N * (unsigned)(a.H * a.W) * 256u);
+    f32x4 xf[4][8];
+    const int X = tx * TO_OW - 1 + l31;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int Y = ty * TO_OH - 1 + 4 * wave + mt;
+        const int ok = (int)((unsigned)Y < (unsigned)a.H) & (int)((unsigned)X < (unsigned)a.W);
+        const unsigned base = (unsigned)(((n * a.H + Y) * a.W + X) * 256 + 16 * kk);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            xf[mt][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? base + 32u * j : 0x80000000u, 0, 0));
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = xf[mt][j][i];
+                if (ACT) v = v > 0.f ? v : slope * v;
+                acc = mfma32(wa[j][i], v, acc);
+            }
+        float* pp = P + ((4 * wave + mt) * TO_RW + l31) * TO_PSTR + 4 * kk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < 3 || kk == 0) *reinterpret_cast<f32x4*>(pp + 8 * q) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+    }
+    __syncthreads();
+    toimage_gather(a, P, n, ty, tx);
+}
+
+static int toimage_common(const SisrConvDesc* d) {
+    const char* sw = getenv("SISR_THIN");                       // A/B switch: SISR_THIN=0 keeps the generic kernels
     if ((sw && sw[0] == '0') || !d) return 0;
     if (d->Cin != 64 || d->Cout != 3 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
-    if (d->x_mode != SISR_X_NHWC || !d->x_bf16 || (d->pro_mode != SISR_PRO_NONE && d->pro_mode != SISR_PRO_ACT)) return 0;
+    if (d->x_mode != SISR_X_NHWC || (d->pro_mode != SISR_PRO_NONE && d->pro_mode != SISR_PRO_ACT)) return 0;
     if (d->y_mode != SISR_Y_NCHW || d->y_bf16 || d->res || d->stat_part || d->bnb_part) return 0;
     if (d->epi_act != SISR_EPI_NONE && d->epi_act != SISR_EPI_TANH) return 0;
-    if (d->Ho != d->H || d->Wo != d->W || d->plan.CK != 32 || d->plan.CoutPad < 3) return 0;
-    if ((int64_t)d->N * d->H * d->W * 128 >= (1ll << 31)) return 0;
+    if (d->Ho != d->H || d->Wo != d->W || d->plan.CoutPad < 3) return 0;
+    if ((int64_t)d->N * d->H * d->W * 256 >= (1ll << 31)) return 0;
     return 1;
+}
+
+// bf16 tensors (behind sisr_conv2d_bf16, descriptor planned by sisr_conv2d_plan_bf16)
+extern "C" int sisr_conv2d_toimage_eligible(const SisrConvDesc* d) {
+    return toimage_common(d) && d->x_bf16 && d->plan.CK == 32;
+}
+// fp32 tensors (behind sisr_conv2d_f32, descriptor planned by sisr_conv2d_plan)
+extern "C" int sisr_conv2d_toimage_f32_eligible(const SisrConvDesc* d) {
+    return toimage_common(d) && !d->x_bf16 && d->plan.CK >= 4 && (64 % d->plan.CK) == 0 && d->plan.PS >= d->plan.CK &&
+           d->plan.KROWP >= 3 * d->plan.PS - (d->plan.PS - d->plan.CK) && d->plan.n_chunk * d->plan.CK == 64;
 }
 
 int sisr_conv2d_toimage_launch(const SisrConvDesc* d, hipStream_t st) {
@@ -124,12 +196,19 @@ int sisr_conv2d_toimage_launch(const SisrConvDesc* d, hipStream_t st) {
     a.x = d->x1; a.wpk = d->wpk; a.bias = d->bias; a.y = d->y;
     a.slope_p = d->pro_slope_p; a.slope = d->pro_slope;
     a.N = d->N; a.H = d->H; a.W = d->W; a.CoutPad = d->plan.CoutPad;
+    a.CK = d->plan.CK; a.PS = d->plan.PS; a.KROWP = d->plan.KROWP;
     a.tanh_epi = d->epi_act == SISR_EPI_TANH;
     a.tiles_x = (d->W + TO_OW - 1) / TO_OW;
     a.tiles_y = (d->H + TO_OH - 1) / TO_OH;
     const dim3 grid(a.tiles_x * a.tiles_y * d->N), block(256);
-    if (d->pro_mode == SISR_PRO_ACT) hipLaunchKernelGGL(conv_toimage_kernel<true>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(conv_toimage_kernel<false>, grid, block, 0, st, a);
+    const bool act = d->pro_mode == SISR_PRO_ACT;
+    if (d->x_bf16) {
+        if (act) hipLaunchKernelGGL(conv_toimage_kernel<true>, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(conv_toimage_kernel<false>, grid, block, 0, st, a);
+    } else {
+        if (act) hipLaunchKernelGGL(conv_toimage_f32_kernel<true>, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(conv_toimage_f32_kernel<false>, grid, block, 0, st, a);
+    }
     SISR_CHECK_LAUNCH();
     return 0;
 }

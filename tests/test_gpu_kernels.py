@@ -1002,3 +1002,29 @@ def test_last_conv_weight_gradient_reads_the_image_gradient_directly(E, L, shape
         assert torch.equal(E.conv_wgrad(p, x_op, dy_op), red['1'])
     finally:
         E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('pro,tanh', [('act', True), ('none', False)])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 13, 31), (1, 96, 96)])
+def test_last_conv_as_gemm_plus_col2im_fp32(E, L, shape, pro, tanh, monkeypatch):
+    """conv_toimage.hip's exact-fp32 variant (fp32 parity build: fp32 NHWC activations in, NCHW fp32 image out) against
+    the generic fp32 kernel (SISR_THIN=0) and F.conv2d at the parity build's tolerance"""
+    n, h, w = shape
+    x = _rand((n, 64, h, w), 251) * 2.0
+    wt = _rand((3, 64, 3, 3), 252, (1.0 / 576) ** 0.5 * 1.7)
+    b = _rand((3,), 253, 0.1)
+    y_ref = F.conv2d(F.leaky_relu(x, 0.25) if pro == 'act' else x, wt, b, padding=1)
+    y_ref = torch.tanh(y_ref) if tanh else y_ref
+    ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 3, 3, 1, 1))
+    p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+    xd = nhwc(x).cuda()
+    op = E.Operand.plain(xd) if pro == 'none' else E.Operand.act(xd, torch.tensor([0.25], device='cuda'))
+    out = {}
+    for sw in ('1', '0'):
+        monkeypatch.setenv('SISR_THIN', sw)
+        out[sw] = E.conv_forward(p, op, bias=ref.bias, y_mode=L.Y_NCHW, epi=L.EPI_TANH if tanh else L.EPI_NONE)[0]
+    assert maxrel(out['1'], y_ref) < 1e-5 and maxrel(out['1'], out['0']) < 1e-5
+    d = L.ConvDesc.from_buffer_copy(p.plans[0])
+    d.x_mode, d.pro_mode, d.y_mode, d.epi_act = L.X_NHWC, L.PRO_ACT if pro == 'act' else L.PRO_NONE, L.Y_NCHW, 0
+    monkeypatch.setenv('SISR_THIN', '1')
+    assert L.lib().sisr_conv2d_toimage_f32_eligible(d) == 1      # (the kernel under test did run)
