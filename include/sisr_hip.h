@@ -203,6 +203,9 @@ int sisr_wgrad_thin_eligible(const SisrWgradDesc *d);
  * by sisr_wgrad_plan_bf16 for the gradient padded to 4 channels) runs on wgrad_toimage.hip behind sisr_conv2d_wgrad_bf16:
  * no 4-channel NHWC copy of the gradient is needed then; same slab layout (sisr_wgrad_bf16_slabs accounts for it). */
 int sisr_wgrad_toimage_eligible(const SisrWgradDesc *d);
+/* ... and with fp32 NHWC activations (fp32 parity build; exact fp32 MFMA, descriptor planned by sisr_wgrad_plan) behind
+ * sisr_conv2d_wgrad_f32; sisr_wgrad_f32_slabs accounts for it */
+int sisr_wgrad_toimage_f32_eligible(const SisrWgradDesc *d);
 int sisr_conv2d_wgrad_f32(const SisrWgradDesc *d, void *stream);
 /* out[i] = sum_s slab[s][i], i < elems (also used for the bias slabs) */
 int sisr_slab_reduce_f32(const float *slab, float *out, int32_t n_slabs, int64_t elems, void *stream);

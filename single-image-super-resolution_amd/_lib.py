@@ -112,6 +112,7 @@ _SIGS = {
     'sisr_wgrad_f32_slabs': [C.POINTER(WgradDesc)],
     'sisr_wgrad_thin_eligible': [C.POINTER(WgradDesc)],
     'sisr_wgrad_toimage_eligible': [C.POINTER(WgradDesc)],
+    'sisr_wgrad_toimage_f32_eligible': [C.POINTER(WgradDesc)],
     'sisr_wgrad_plan_bf16': [C.POINTER(WgradDesc), _i32],
     'sisr_conv2d_wgrad_bf16': [C.POINTER(WgradDesc), _f],
     'sisr_tr16_selftest': [_f, _f],

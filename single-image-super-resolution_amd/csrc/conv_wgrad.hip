@@ -269,6 +269,8 @@ extern "C" int sisr_wgrad_trunk_f32_eligible(const SisrWgradDesc* d);
 int sisr_wgrad_trunk_f32_launch(const SisrWgradDesc* d, hipStream_t st);      // wgrad_trunk_f32.hip
 extern "C" int sisr_wgrad_thin_eligible(const SisrWgradDesc* d);
 int sisr_wgrad_thin_launch(const SisrWgradDesc* d, hipStream_t st);           // wgrad_thin.hip
+extern "C" int sisr_wgrad_toimage_f32_eligible(const SisrWgradDesc* d);
+int sisr_wgrad_toimage_f32_launch(const SisrWgradDesc* d, hipStream_t st);    // wgrad_toimage.hip
 
 extern "C" int sisr_conv2d_wgrad_f32(const SisrWgradDesc* d, void* stream) {
     if (!d || !d->x1 || !d->g1 || !d->slab) return SISR_E_BADARG;
@@ -280,6 +282,7 @@ extern "C" int sisr_conv2d_wgrad_f32(const SisrWgradDesc* d, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (sisr_wgrad_trunk_f32_eligible(d)) return sisr_wgrad_trunk_f32_launch(d, st);
     if (sisr_wgrad_thin_eligible(d)) return sisr_wgrad_thin_launch(d, st);      // bf16 build: the first conv (3-channel image)
+    if (sisr_wgrad_toimage_f32_eligible(d)) return sisr_wgrad_toimage_f32_launch(d, st);    // the last conv (64 -> 3), fp32 tensors
     switch (d->KH * d->NT) {
         case 1: return launch_wgrad<1>(d, st);
         case 2: return launch_wgrad<2>(d, st);

@@ -261,3 +261,203 @@ int sisr_wgrad_toimage_launch(const SisrWgradDesc* d, hipStream_t st) {
     if (act) return tanhb ? wi_launch<true, true>(a, grid, st) : wi_launch<true, false>(a, grid, st);
     return tanhb ? wi_launch<false, true>(a, grid, st) : wi_launch<false, false>(a, grid, st);
 }
+
+// ---- the same layer with fp32 tensors (fp32 parity build): exact v_mfma_f32_32x32x2_f32 -------------------------------------
+// D[ci 64][n = (ky', kx', co), 27 of 32] over K = pixels, 2 per MFMA.  An fp32 MFMA operand is one float per lane, so both
+// operands are plain 4-byte LDS reads: A[ci][pixel] from the pixel-major x tile (lanes = consecutive channels), B[pixel][n]
+// from the planar gradient halo at (row + ky', column + kx' + 3) -- no transposing reads, no shifted copies.  The generic
+// fp32 kernel (conv_wgrad.hip) pads the 3 couts to 32 MFMA columns for each of the 9 x 64 K rows: ~340 us; here 590 K
+// MFMAs (16 us of matrix time) over 151 MB of activations.  Slab in the generic fp32 layout [chunk][ky][kx * PS + cl][CoutPad].
+#define WJ_PS 64                           // floats per x pixel in LDS
+#define WJ_XBYTES (WI_TH * WI_TW * WJ_PS * 4)     // 65536
+#define WJ_GW 40                           // gradient halo columns (origin = tile origin - 4: 16-byte aligned rows)
+#define WJ_GBYTES (3 * WI_GROWS * WJ_GW * 4)      // 4800
+#define WJ_XITEMS 16                       // 16-byte x items per thread and tile
+#define WJ_GITEMS 5                        // gradient halo elements per thread: 1200 = 4.7 x 256
+
+struct WToImageF32Args {
+    const float *x, *g1, *g2;
+    float *slab, *bias_slab;
+    const float* slope_p;
+    float slope;
+    int N, H, W;
+    int tiles_x, per_img, total;
+    int CK, PS, KROWP, CoutPad, slab_elems;
+    long long slab_stride;
+};
+
+template <bool ACT, bool TANHB>
+__global__ void __launch_bounds__(256, 1) wgrad_toimage_f32_kernel(const WToImageF32Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float* xs = reinterpret_cast<float*>(lds);                     // [pixel 256][64]
+    float* gs = reinterpret_cast<float*>(lds + WJ_XBYTES);         // [co 3][row 10][col 40]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kk = lane >> 5;
+    const float slope = a.slope_p ? a.slope_p[0] : a.slope;
+
+    int bbase;
+    {
+        const int nn = l31 < 27 ? l31 : 0;
+        const int kyf = nn / 9, kxf = (nn - 9 * kyf) / 3, co = nn - 9 * kyf - 3 * kxf;
+        bbase = (co * WI_GROWS + kyf) * WJ_GW + kxf + 3 + kk;
+    }
+    const unsigned plane = (unsigned)(a.H * a.W);
+    const __amdgpu_buffer_rsrc_t rg = sisr_rsrc(a.g1, (unsigned)a.N * 3u * plane * 4u),
+                                 ry = sisr_rsrc(TANHB ? a.g2 : a.g1, (unsigned)a.N * 3u * plane * 4u);
+    const __amdgpu_buffer_rsrc_t rx = sisr_rsrc(a.x, (unsigned)a.N * plane * 256u);
+    // x: item i of a thread = 16-byte group (tid + 256 i): pixel = group / 16, channels 4 (group % 16) ..
+    // gradient halo: element (tid + 256 k) of [co][row][col]
+    int g_co[WJ_GITEMS], g_row[WJ_GITEMS], g_col[WJ_GITEMS];
+#pragma unroll
+    for (int k = 0; k < WJ_GITEMS; ++k) {
+        const int idx = tid + 256 * k;
+        g_co[k] = idx / (WI_GROWS * WJ_GW);
+        const int rem = idx - g_co[k] * (WI_GROWS * WJ_GW);
+        g_row[k] = rem / WJ_GW;
+        g_col[k] = rem - g_row[k] * WJ_GW;
+    }
+    f32x4 sx[WJ_XITEMS];
+    float sg[WJ_GITEMS], sy[WJ_GITEMS];
+    float bsum[3] = {0.f, 0.f, 0.f};
+
+    auto issue = [&](int T) {
+        const int n = T / a.per_img, r = T - n * a.per_img;
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        const int live = T < a.total;
+#pragma unroll
+        for (int k = 0; k < WJ_GITEMS; ++k) {
+            const int Y = ty * WI_TH - 1 + g_row[k], X = tx * WI_TW - 4 + g_col[k];
+            const int ok = live & (int)(g_co[k] < 3) & (int)((unsigned)Y < (unsigned)a.H) & (int)((unsigned)X < (unsigned)a.W);
+            const unsigned voff = ok ? (unsigned)((((n * 3 + g_co[k]) * a.H + Y) * a.W + X) * 4) : 0x80000000u;
+            sg[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, voff, 0, 0));
+            if (TANHB) sy[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, voff, 0, 0));
+        }
+        const int origin = ((n * a.H + ty * WI_TH) * a.W + tx * WI_TW) * 256;
+#pragma unroll
+        for (int i = 0; i < WJ_XITEMS; ++i) {
+            const int grp = tid + 256 * i, p = grp >> 4, c4 = grp & 15;
+            const unsigned voff = live ? (unsigned)(origin + ((p >> 5) * a.W + (p & 31)) * 256 + c4 * 16) : 0x80000000u;
+            sx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0));
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < WJ_GITEMS; ++k) {
+            const float e = TANHB ? sg[k] * (1.f - sy[k] * sy[k]) : sg[k];
+            if (g_co[k] < 3) gs[tid + 256 * k] = e;
+            // bias partial: the tile's own pixels = halo rows 1 .. 8, halo columns 4 .. 35
+            const bool mine = g_row[k] >= 1 && g_row[k] <= WI_TH && g_col[k] >= 4 && g_col[k] < 4 + WI_TW;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) bsum[c] += (mine && g_co[k] == c) ? e : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < WJ_XITEMS; ++i) {
+            f32x4 v = sx[i];
+            if (ACT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : slope * v[j];
+            }
+            *reinterpret_cast<f32x4*>(xs + (tid + 256 * i) * 4) = v;      // [pixel][64]: group index = pixel * 16 + c4
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mh][i] = 0.f;
+
+    int T = blockIdx.x;
+    issue(T);
+    commit();
+    __syncthreads();
+    for (; T < a.total; T += gridDim.x) {
+        issue(T + gridDim.x);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * wave + rr;
+#pragma unroll
+            for (int sxp = 0; sxp < 16; ++sxp) {                     // pixels (r, 2 sxp + kk)
+                const float* xp = xs + (r * WI_TW + 2 * sxp + kk) * WJ_PS + l31;
+                const float b = gs[bbase + r * WJ_GW + 2 * sxp];
+                acc[0] = mfma32(xp[0], b, acc[0]);
+                acc[1] = mfma32(xp[32], b, acc[1]);
+            }
+        }
+        __syncthreads();
+        commit();
+        __syncthreads();
+    }
+
+    float* part = reinterpret_cast<float*>(lds);                  // [wave][ci 64][n 32]
+    float* bred = part + 4 * 64 * 32;                              // [256][3] bias partials
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[(wave * 64 + 32 * mh + mfma_row(i, lane)) * 32 + l31] = acc[mh][i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bred[tid * 3 + c] = bsum[c];
+    __syncthreads();
+    float* sl = a.slab + (long long)blockIdx.x * a.slab_stride;
+    for (int idx = tid; idx < a.slab_elems; idx += 256) {
+        const int co = idx % a.CoutPad, t = idx / a.CoutPad, krow = t % a.KROWP, t2 = t / a.KROWP, ky = t2 % 3, chunk = t2 / 3;
+        const int kx = krow / a.PS, cl = krow - kx * a.PS;
+        float v = 0.f;
+        if (co < 3 && kx < 3 && cl < a.CK) {
+            const int n = (2 - ky) * 9 + (2 - kx) * 3 + co, ci = chunk * a.CK + cl;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += part[(w * 64 + ci) * 32 + n];
+        }
+        sl[idx] = v;
+    }
+    if (a.bias_slab != nullptr && tid < a.CoutPad) {
+        float s = 0.f;
+        if (tid < 3)
+            for (int i = 0; i < 256; ++i) s += bred[i * 3 + tid];
+        a.bias_slab[(long long)blockIdx.x * a.slab_stride + tid] = s;
+    }
+}
+
+extern "C" int sisr_wgrad_toimage_f32_eligible(const SisrWgradDesc* d) {
+    const char* sw = getenv("SISR_THIN");                       // A/B switch: SISR_THIN=0 keeps the generic kernel
+    if ((sw && sw[0] == '0') || !d) return 0;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
+    if (d->Cin != 64 || d->Cout != 3 || d->CoutPad < 3 || d->CoutPad > 256 || d->CK < 1 || d->n_chunk * d->CK != 64) return 0;
+    if (d->PS < d->CK || d->KROWP < 2 * d->PS + d->CK || d->slab_elems != d->n_chunk * 3 * d->KROWP * d->CoutPad) return 0;
+    if (d->x_mode != SISR_X_NHWC || d->x_bf16 || (d->pro_mode != SISR_PRO_NONE && d->pro_mode != SISR_PRO_ACT)) return 0;
+    if (d->g_mode != SISR_X_NCHW || d->g_bf16 || (d->gpro_mode != SISR_PRO_NONE && d->gpro_mode != SISR_PRO_TANH_BWD)) return 0;
+    if (d->Ho != d->H || d->Wo != d->W || (d->H % WI_TH) || (d->W % WI_TW)) return 0;
+    if ((int64_t)d->N * d->H * d->W * 256 >= (1ll << 31)) return 0;
+    return 1;
+}
+
+template <bool ACT, bool TANHB>
+static int wj_launch(const WToImageF32Args& a, int grid, hipStream_t st) {
+    constexpr int lds_bytes = WJ_XBYTES + WJ_GBYTES + 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_toimage_f32_kernel<ACT, TANHB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_toimage_f32_kernel<ACT, TANHB>), dim3(grid), dim3(256), lds_bytes, st, a);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+int sisr_wgrad_toimage_f32_launch(const SisrWgradDesc* d, hipStream_t st) {
+    const bool act = d->pro_mode == SISR_PRO_ACT, tanhb = d->gpro_mode == SISR_PRO_TANH_BWD;
+    if (tanhb && !d->g2) return SISR_E_BADARG;
+    WToImageF32Args a;
+    a.x = d->x1; a.g1 = d->g1; a.g2 = d->g2; a.slab = d->slab; a.bias_slab = d->bias_slab;
+    a.slope_p = d->pro_slope_p; a.slope = d->pro_slope;
+    a.N = d->N; a.H = d->H; a.W = d->W;
+    a.tiles_x = d->W / WI_TW;
+    a.per_img = a.tiles_x * (d->H / WI_TH);
+    a.total = a.per_img * d->N;
+    a.CK = d->CK; a.PS = d->PS; a.KROWP = d->KROWP; a.CoutPad = d->CoutPad; a.slab_elems = d->slab_elems;
+    a.slab_stride = d->slab_stride;
+    const int grid = wi_grid(d);
+    if (act) return tanhb ? wj_launch<true, true>(a, grid, st) : wj_launch<true, false>(a, grid, st);
+    return tanhb ? wj_launch<false, true>(a, grid, st) : wj_launch<false, false>(a, grid, st);
+}

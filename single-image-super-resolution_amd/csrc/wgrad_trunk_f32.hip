@@ -250,11 +250,14 @@ extern "C" int sisr_wgrad_trunk_f32_eligible(const SisrWgradDesc* d) {
 // slabs a launch of this descriptor writes (rows of `slab` at slab_stride)
 extern "C" int sisr_wgrad_thin_eligible(const SisrWgradDesc* d);
 int sisr_wgrad_thin_slabs(const SisrWgradDesc* d);                            // wgrad_thin.hip
+extern "C" int sisr_wgrad_toimage_f32_eligible(const SisrWgradDesc* d);
+int sisr_wgrad_toimage_slabs(const SisrWgradDesc* d);                         // wgrad_toimage.hip
 
 extern "C" int sisr_wgrad_f32_slabs(const SisrWgradDesc* d) {
     if (!d) return SISR_E_BADARG;
     if (sisr_wgrad_trunk_f32_eligible(d)) return wf_grid(d);
-    return sisr_wgrad_thin_eligible(d) ? sisr_wgrad_thin_slabs(d) : d->n_slabs;
+    if (sisr_wgrad_thin_eligible(d)) return sisr_wgrad_thin_slabs(d);
+    return sisr_wgrad_toimage_f32_eligible(d) ? sisr_wgrad_toimage_slabs(d) : d->n_slabs;
 }
 
 template <int GPRO>

@@ -1028,3 +1028,43 @@ def test_last_conv_as_gemm_plus_col2im_fp32(E, L, shape, pro, tanh, monkeypatch)
     d.x_mode, d.pro_mode, d.y_mode, d.epi_act = L.X_NHWC, L.PRO_ACT if pro == 'act' else L.PRO_NONE, L.Y_NCHW, 0
     monkeypatch.setenv('SISR_THIN', '1')
     assert L.lib().sisr_conv2d_toimage_f32_eligible(d) == 1      # (the kernel under test did run)
+
+
+@pytest.mark.parametrize('pro,tanh', [('act', True), ('none', False)])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 64), (1, 96, 96)])
+def test_last_conv_weight_gradient_fp32(E, L, shape, pro, tanh, monkeypatch):
+    """wgrad_toimage.hip's exact-fp32 variant (fp32 parity build) against the generic fp32 kernel (SISR_THIN=0) and
+    autograd at the parity build's tolerance; padding entries of the packed slab are zero"""
+    n, h, w = shape
+    x = _rand((n, 64, h, w), 261) * 2.0
+    wt = _rand((3, 64, 3, 3), 262, (1.0 / 576) ** 0.5 * 1.7)
+    b = _rand((3,), 263, 0.1)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pre = F.conv2d(F.leaky_relu(x, 0.25) if pro == 'act' else x, wr, br, padding=1)
+    y = torch.tanh(pre) if tanh else pre
+    g = _rand((n, 3, h, w), 264)
+    y.backward(g)
+    ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 3, 3, 1, 1))
+    p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+    xd = nhwc(x).cuda()
+    x_op = E.Operand.plain(xd) if pro == 'none' else E.Operand.act(xd, torch.tensor([0.25], device='cuda'))
+    if tanh:
+        dy_op = E.Operand(g.cuda(), (n, h, w, 3), pro=L.PRO_TANH_BWD, mode=L.X_NCHW, x2=y.detach().cuda())
+    else:
+        dy_op = E.Operand.plain(g.cuda(), dims=(n, h, w, 3), mode=L.X_NCHW)
+    wgd = L.WgradDesc.from_buffer_copy(p.plans[2])
+    x_op.fill(wgd)
+    dy_op.fill(wgd, g=True)
+    monkeypatch.setenv('SISR_THIN', '1')
+    assert L.lib().sisr_wgrad_toimage_f32_eligible(wgd) == 1      # (the kernel under test does run)
+    grads = {}
+    for sw in ('1', '0'):
+        monkeypatch.setenv('SISR_THIN', sw)
+        red = E.conv_wgrad(p, x_op, dy_op)
+        wg = E.WeightGradBatch()
+        wg.add(p, red)
+        grads[sw] = wg.run()[id(ref)]
+    for sw in ('1', '0'):
+        assert maxrel(grads[sw][0], wr.grad) < 2e-5 and maxrel(grads[sw][1], br.grad) < 2e-5, sw
+    monkeypatch.setenv('SISR_THIN', '1')
+    assert torch.equal(E.conv_wgrad(p, x_op, dy_op), E.conv_wgrad(p, x_op, dy_op))
