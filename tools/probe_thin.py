@@ -1,7 +1,8 @@
 """Launch time of the thin-layer kernels against the batch size (fixed cost vs per-tile cost): HIP-event timing of the
 engine calls for N = 16, 32, 48 at the bench geometry (LR 96, HR 192).  usage: python tools/probe_thin.py"""
 import os, sys
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 from gpu_helpers import pkg, FakeConv, nhwc
 E, L = pkg('engine'), pkg('_lib')
@@ -11,7 +12,7 @@ dev = 'cuda'
 rnd = lambda *s: torch.rand(s, device=dev) * 2 - 1
 
 
-def timed(fn, iters=60):
+def timed(fn, iters=int(os.environ.get('PROBE_ITERS', '60'))):
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
@@ -24,7 +25,7 @@ def timed(fn, iters=60):
     return a.elapsed_time(b) / iters * 1e3
 
 
-for n in (16, 32, 48):
+for n in ([int(os.environ['PROBE_N'])] if 'PROBE_N' in os.environ else (16, 32, 48)):
     row = []
     # first conv (9x9, 3 -> 64, LR 96): forward + weight gradient
     ref = FakeConv(rnd(64, 3, 9, 9) * 0.1, rnd(64) * 0.1, E.ConvGeom(3, 64, 9, 1, 4))
