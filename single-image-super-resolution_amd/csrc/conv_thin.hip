@@ -45,7 +45,7 @@ struct ThinArgs {
     const float *x1, *x2, *wpk, *bias;
     void* y;
     int N, H, W;
-    int tiles_x, per_img, total;
+    int tiles_x, per_img, total, rounds;
 };
 
 template <int KS, bool TANHB>
@@ -106,12 +106,15 @@ __global__ void __launch_bounds__(256, 1) conv_thin_kernel(const ThinArgs a) {
         hx[k] = id - hy[k] * IH;
         rel[k] = ((hy[k] - PAD) * a.W + hx[k] - PAD) * 4;      // byte offset from the tile's first pixel, within a plane
     }
+    // a workgroup walks a CONTIGUOUS run of tiles (neighbours along x): the 128-byte lines of the planar image that two
+    // neighbouring halos share are then fetched by one XCD's L2 once, not by two XCDs at the same moment
+    const int t_first = blockIdx.x * a.rounds, t_end = min(t_first + a.rounds, a.total);
     float sv[ITEMS][3], sw[ITEMS][3];
     auto issue = [&](int T) {
         const int n = T / a.per_img, r = T - n * a.per_img;
         const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
         const int origin = ((n * 3 * a.H + ty * TN_T) * a.W + tx * TN_T) * 4;
-        const int live = T < a.total;
+        const int live = T < t_end;
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
             const int y = ty * TN_T - PAD + hy[k], x = tx * TN_T - PAD + hx[k];
@@ -142,16 +145,16 @@ __global__ void __launch_bounds__(256, 1) conv_thin_kernel(const ThinArgs a) {
     // B fragment of (halo row hh, K slice j): pixels (8g + hh + prow, px + 4j + 2kk .. +1)
     const int b_base = ((8 * g + prow) * IW + px + 2 * kk) * 8;
 
-    int T = blockIdx.x;
+    int T = t_first;
     issue(T);
     commit(lds);
     __syncthreads();
-    issue(T + gridDim.x);
+    issue(T + 1);
     int cur = 0;
     // per tile: MFMA phase | commit the next tile's halo (requested a tile ago) | request the one after | stores | barrier.
     // (Requests sit BEFORE the stores: the staging registers double as store operands, and a load into a register a
     // pending store still reads has to wait for that store -- this way the stores have a whole MFMA phase to drain.)
-    for (; T < a.total; T += gridDim.x, cur ^= 1) {
+    for (; T < t_end; ++T, cur ^= 1) {
         f32x16 acc[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -174,7 +177,7 @@ __global__ void __launch_bounds__(256, 1) conv_thin_kernel(const ThinArgs a) {
             }
         __builtin_amdgcn_sched_barrier(0);        // (keeps the commit's conversions -- and their wait for the loads -- below the MFMAs)
         commit(lds + (cur ^ 1) * HALO);
-        issue(T + 2 * gridDim.x);
+        issue(T + 2);
         // ---- epilogue: registers 4q..4q+3 of a lane = couts 8q + 4kk .. +3 of its pixel; swapping the halves of register
         // groups (q, q + 1) between lanes l and l + 32 leaves 8 consecutive couts (16 bytes) in every lane -----------------
         const int n = T / a.per_img, r = T - n * a.per_img;
@@ -230,6 +233,7 @@ int sisr_conv2d_thin_launch(const SisrConvDesc* d, hipStream_t st) {
     a.total = a.per_img * d->N;
     // equal shares: every workgroup walks ceil(total / cus) tiles
     const int rounds = (a.total + cus - 1) / cus;
+    a.rounds = rounds;
     const dim3 grid((a.total + rounds - 1) / rounds), block(256);
     if (d->KH == 9) {
         if (tanhb) hipLaunchKernelGGL((conv_thin_kernel<9, true>), grid, block, 0, st, a);
