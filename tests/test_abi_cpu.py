@@ -71,3 +71,42 @@ def test_modules_mirror_reference_state_dict_layout():
     g1 = mp_.GeneratorSuffix(mp_.GeneratorProgresiveBase(1, 64), 64)
     g3 = mp_.GeneratorSuffix(mp_.GeneratorSuffix(g1.beginning, 16).beginning, 4)
     assert list(g3.state_dict().keys()) == keys
+
+
+def test_shape_specific_kernels_claim_exactly_their_descriptors(monkeypatch):
+    """Host-side dispatch rules of the thin-layer kernels (pure host code, no GPU): the generator's first / last conv
+    descriptors are claimed at the bench sizes, and ragged sizes, other prologues and SISR_THIN=0 fall back to the
+    generic kernels (model_generator.py:32, 52)."""
+    E, L = _pkg('engine'), _pkg('_lib')
+    lib = L.lib()
+    monkeypatch.delenv('SISR_THIN', raising=False)
+    # first conv (9x9, 3 -> 64): fp32 planner descriptors; the bf16 build stores its output as bf16
+    f, _, g, _ = E.ConvGeom(3, 64, 9, 1, 4).plans(16, 96, 96)
+    f = L.ConvDesc.from_buffer_copy(f)
+    f.x_mode, f.y_mode, f.y_bf16 = L.X_NCHW, L.Y_NHWC, 1
+    assert lib.sisr_conv2d_thin_eligible(f) == 1
+    f.y_bf16 = 0
+    assert lib.sisr_conv2d_thin_eligible(f) == 0             # fp32 output: the parity build keeps the exact-fp32 kernel
+    f.y_bf16, f.pro_mode = 1, L.PRO_ACT
+    assert lib.sisr_conv2d_thin_eligible(f) == 0
+    g = L.WgradDesc.from_buffer_copy(g)
+    g.x_mode, g.g_mode, g.g_bf16, g.gpro_mode = L.X_NCHW, L.X_NHWC, 1, L.PRO_ACT_BWD
+    assert lib.sisr_wgrad_thin_eligible(g) == 1
+    assert lib.sisr_wgrad_f32_slabs(g) <= 256 * 2            # one slab per workgroup of the persistent kernel
+    g48 = L.WgradDesc.from_buffer_copy(E.ConvGeom(3, 64, 9, 1, 4).plans(16, 48, 48)[2])
+    g48.x_mode, g48.g_mode, g48.g_bf16, g48.gpro_mode = L.X_NCHW, L.X_NHWC, 1, L.PRO_ACT_BWD
+    assert lib.sisr_wgrad_thin_eligible(g48) == 0            # W % 32 != 0
+    # last conv (3x3, 64 -> 3) with fp32 tensors: forward and weight gradient
+    f3, _, g3, _ = E.ConvGeom(64, 3, 3, 1, 1).plans(16, 192, 192)
+    f3 = L.ConvDesc.from_buffer_copy(f3)
+    f3.x_mode, f3.y_mode, f3.pro_mode, f3.epi_act = L.X_NHWC, L.Y_NCHW, L.PRO_ACT, L.EPI_TANH
+    assert lib.sisr_conv2d_toimage_f32_eligible(f3) == 1 and lib.sisr_conv2d_toimage_eligible(f3) == 0
+    f3.y_mode = L.Y_NHWC
+    assert lib.sisr_conv2d_toimage_f32_eligible(f3) == 0
+    g3 = L.WgradDesc.from_buffer_copy(g3)
+    g3.x_mode, g3.pro_mode, g3.g_mode, g3.gpro_mode = L.X_NHWC, L.PRO_ACT, L.X_NCHW, L.PRO_TANH_BWD
+    assert lib.sisr_wgrad_toimage_f32_eligible(g3) == 1 and lib.sisr_wgrad_toimage_eligible(g3) == 0
+    monkeypatch.setenv('SISR_THIN', '0')
+    f.pro_mode, f3.y_mode = L.PRO_NONE, L.Y_NCHW
+    assert lib.sisr_conv2d_thin_eligible(f) == 0 and lib.sisr_wgrad_thin_eligible(g) == 0
+    assert lib.sisr_conv2d_toimage_f32_eligible(f3) == 0 and lib.sisr_wgrad_toimage_f32_eligible(g3) == 0
