@@ -35,7 +35,7 @@ struct ToImageArgs {
     float slope;
     int N, H, W, CoutPad, tanh_epi;
     int CK, PS, KROWP;                // fp32 variant: layout of the packed fp32 weight image
-    int tiles_x, tiles_y;
+    int tiles_x, tiles_y, total, per_xcd;
 };
 
 // col2im gather of the 14 x 30 interior of a region, x fastest (coalesced NCHW stores)
@@ -58,7 +58,11 @@ template <bool ACT>
 __global__ void __launch_bounds__(256, 2) conv_toimage_kernel(const ToImageArgs a) {
     __shared__ __attribute__((aligned(16))) float P[TO_RH * TO_RW * TO_PSTR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kk = lane >> 5;
-    const int tx = blockIdx.x % a.tiles_x, t2 = blockIdx.x / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
+    // workgroup b runs on XCD b % 8: every XCD gets a contiguous eighth of the regions, so the border pixels two
+    // neighbouring regions both read come out of ONE L2
+    const int tile = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+    if (tile >= a.total) return;
+    const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
     const float slope = a.slope_p ? a.slope_p[0] : a.slope;
 
     // ---- A fragments: row m = co * 9 + tap of the 27 x 64 weight matrix, packed bf16 image [chunk 32][cout][tap * 32 + cl]
@@ -120,7 +124,11 @@ template <bool ACT>
 __global__ void __launch_bounds__(256, 2) conv_toimage_f32_kernel(const ToImageArgs a) {
     __shared__ __attribute__((aligned(16))) float P[TO_RH * TO_RW * TO_PSTR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kk = lane >> 5;
-    const int tx = blockIdx.x % a.tiles_x, t2 = blockIdx.x / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
+    // workgroup b runs on XCD b % 8: every XCD gets a contiguous eighth of the regions, so the border pixels two
+    // neighbouring regions both read come out of ONE L2
+    const int tile = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+    if (tile >= a.total) return;
+    const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
     const float slope = a.slope_p ? a.slope_p[0] : a.slope;
     // A fragments from the packed fp32 image [chunk][ky][cout][kx * PS + cl]
     float wa[8][4];
@@ -200,7 +208,9 @@ int sisr_conv2d_toimage_launch(const SisrConvDesc* d, hipStream_t st) {
     a.tanh_epi = d->epi_act == SISR_EPI_TANH;
     a.tiles_x = (d->W + TO_OW - 1) / TO_OW;
     a.tiles_y = (d->H + TO_OH - 1) / TO_OH;
-    const dim3 grid(a.tiles_x * a.tiles_y * d->N), block(256);
+    a.total = a.tiles_x * a.tiles_y * d->N;
+    a.per_xcd = (a.total + 7) / 8;
+    const dim3 grid(8 * a.per_xcd), block(256);
     const bool act = d->pro_mode == SISR_PRO_ACT;
     if (d->x_bf16) {
         if (act) hipLaunchKernelGGL(conv_toimage_kernel<true>, grid, block, 0, st, a);
