@@ -619,17 +619,10 @@ extern "C" int sisr_conv2d_plan_bf16(SisrConvDesc* d) {
     return 0;
 }
 
-// (lds_max: one process drives one GPU from one thread -- the design of this path; a multi-device / multi-thread
-// host would need this per device)
 template <int MSUB, int NSUB, int TAG, bool XBF, bool YBF>
 static int launch_conv_bf16_t(const SisrConvDesc* d, hipStream_t st) {
-    static int lds_max = 64 * 1024;
-    if (d->plan.lds_bytes > lds_max) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bf16_kernel<MSUB, NSUB, TAG, XBF, YBF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, d->plan.lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        lds_max = d->plan.lds_bytes;
-    }
+    static SisrLdsCap cap;
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&conv_mfma_bf16_kernel<MSUB, NSUB, TAG, XBF, YBF>), d->plan.lds_bytes, 64 * 1024)) return e;
     const dim3 grid(d->plan.tiles_x * d->plan.tiles_y, d->plan.n_groups, d->plan.CoutPad / (NSUB * 32));
     hipLaunchKernelGGL((conv_mfma_bf16_kernel<MSUB, NSUB, TAG, XBF, YBF>), grid, dim3(SISR_BLOCK), d->plan.lds_bytes, st, *d);
     SISR_CHECK_LAUNCH();

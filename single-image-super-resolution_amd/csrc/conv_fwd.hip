@@ -404,13 +404,8 @@ extern "C" int sisr_conv2d_plan(SisrConvDesc* d) {
 
 template <int MSUB, int NSUB, int TAG>
 static int launch_conv(const SisrConvDesc* d, hipStream_t st) {
-    static int lds_max = 64 * 1024;   // raise the dynamic-LDS cap only when a plan needs it
-    if (d->plan.lds_bytes > lds_max) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<MSUB, NSUB, TAG>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, d->plan.lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        lds_max = d->plan.lds_bytes;
-    }
+    static SisrLdsCap cap;   // raise the dynamic-LDS cap only when a plan needs it
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&conv_mfma_f32_kernel<MSUB, NSUB, TAG>), d->plan.lds_bytes, 64 * 1024)) return e;
     const dim3 grid(d->plan.n_tiles, d->plan.CoutPad / (NSUB * 32));
     hipLaunchKernelGGL((conv_mfma_f32_kernel<MSUB, NSUB, TAG>), grid, dim3(SISR_BLOCK), d->plan.lds_bytes, st, *d);
     SISR_CHECK_LAUNCH();

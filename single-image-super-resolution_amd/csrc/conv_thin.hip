@@ -216,13 +216,7 @@ extern "C" int sisr_conv2d_thin_eligible(const SisrConvDesc* d) {
 }
 
 int sisr_conv2d_thin_launch(const SisrConvDesc* d, hipStream_t st) {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return SISR_E_BADARG;
-        cus = pr.multiProcessorCount;
-    }
+    const int cus = sisr_cu_slots();
     const bool tanhb = d->pro_mode == SISR_PRO_TANH_BWD;
     if (tanhb && !d->x2) return SISR_E_BADARG;
     ThinArgs a;

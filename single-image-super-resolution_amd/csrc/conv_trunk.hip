@@ -751,14 +751,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
 static int trunk_groups(const SisrConvDesc* d) { return d->Cout == 256 ? 4 : 1; }
 static int trunk_grid(const SisrConvDesc* d) {
     const int total = d->N * (d->H / TK_TH) * (d->W / TK_TW);
-    static int cus = 0;                         // (one process drives one GPU: queried once)
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-        else
-            cus = 256;
-    }
+    const int cus = sisr_cu_slots();
     int n_cu = cus;
     // equal shares: ceil(total / rounds) workgroups, rounds = ceil(total / (CUs x workgroups per CU))
     int per_cu = 1;
@@ -810,13 +803,8 @@ extern "C" int sisr_conv2d_bf16_parts(const SisrConvDesc* d) {
 template <int PRO>
 static int launch_trunk_fwd(const TrunkArgs& a, int grid, hipStream_t st) {
     constexpr int lds_bytes = 2 * TK_HALO_BYTES + 4 * 32 * TK_YS * 2 + 4 * 32 * 3 * 4 + 128 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_trunk_fwd_kernel<PRO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static SisrLdsCap cap;
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&conv_trunk_fwd_kernel<PRO>), lds_bytes)) return e;
     hipLaunchKernelGGL((conv_trunk_fwd_kernel<PRO>), dim3(grid), dim3(TK_THREADS), lds_bytes, st, a);
     SISR_CHECK_LAUNCH();
     return 0;
@@ -825,13 +813,8 @@ static int launch_trunk_fwd(const TrunkArgs& a, int grid, hipStream_t st) {
 template <int PRO>
 static int launch_trunk_bwd(const TrunkArgs& a, int grid, bool images, hipStream_t st) {
     const int lds_bytes = 2 * TK_HALO_BYTES + 4 * 32 * TK_YS * 2 + TK_RED_BYTES + (images ? 4 * TK_IMG : 0);
-    static int lds_max = 0;
-    if (lds_bytes > lds_max) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_trunk_bwd_kernel<PRO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        lds_max = lds_bytes;
-    }
+    static SisrLdsCap cap;
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&conv_trunk_bwd_kernel<PRO>), lds_bytes, 0)) return e;
     hipLaunchKernelGGL((conv_trunk_bwd_kernel<PRO>), dim3(grid), dim3(TK_THREADS), lds_bytes, st, a);
     SISR_CHECK_LAUNCH();
     return 0;

@@ -443,14 +443,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
 // ---- host ----------------------------------------------------------------------------------------------------------
 static int cf_streams(const SisrConvDesc* d) {
     const int total = d->N * (d->H / CF_TH) * (d->W / CF_TW);
-    static int cus = 0;                         // (one process drives one GPU: queried once)
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-        else
-            cus = 256;
-    }
+    const int cus = sisr_cu_slots();
     const int slots = std::max(1, cus / 2);     // two workgroups (the cout halves) per pixel-tile stream
     const int rounds = (total + slots - 1) / slots;
     return (total + rounds - 1) / rounds;       // equal shares
@@ -496,13 +489,8 @@ extern "C" int sisr_conv2d_f32_bnb_parts(const SisrConvDesc* d) {
 template <int PRO>
 static int launch_cf(const CTrunkF32Args& a, hipStream_t st) {
     constexpr int lds_bytes = 2 * CF_WCHUNK_BYTES + 2 * CF_HALO_BYTES + 4 * 32 * 3 * 4 + 128 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_trunk_f32_kernel<PRO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static SisrLdsCap cap;
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&conv_trunk_f32_kernel<PRO>), lds_bytes)) return e;
     hipLaunchKernelGGL((conv_trunk_f32_kernel<PRO>), dim3(2 * a.streams), dim3(CF_THREADS), lds_bytes, st, a);
     SISR_CHECK_LAUNCH();
     return 0;

@@ -252,13 +252,8 @@ extern "C" int sisr_wgrad_plan(SisrWgradDesc* d, int32_t max_pixel_blocks) {
 
 template <int NACC>
 static int launch_wgrad(const SisrWgradDesc* d, hipStream_t st) {
-    static int lds_max = 64 * 1024;
-    if (d->lds_bytes > lds_max) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_f32_kernel<NACC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        lds_max = d->lds_bytes;
-    }
+    static SisrLdsCap cap;
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&wgrad_mfma_f32_kernel<NACC>), d->lds_bytes, 64 * 1024)) return e;
     const dim3 grid(d->grid_x, d->n_chunk * (d->CoutPad / (d->NJ * 32)));
     hipLaunchKernelGGL(wgrad_mfma_f32_kernel<NACC>, grid, dim3(SISR_BLOCK), d->lds_bytes, st, *d);
     SISR_CHECK_LAUNCH();

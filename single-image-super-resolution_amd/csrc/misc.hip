@@ -2,6 +2,7 @@
 // parity test so that a wrong operand/accumulator map is reported as such).
 #include "sisr_dev.h"
 
+#include <cstdlib>
 #include <cstring>
 
 // C[32][32] = A[32][K=8] * B[8][32] with asymmetric integer data; out row-major [row][col]
@@ -25,6 +26,30 @@ extern "C" int sisr_mfma_selftest(float* out_dev, void* stream) {
     hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), out_dev);
     SISR_CHECK_LAUNCH();
     return 0;
+}
+
+int sisr_device_index() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < SISR_MAX_DEVICES ? dev : SISR_MAX_DEVICES - 1;
+}
+
+int sisr_cu_slots() {
+    static int cus[SISR_MAX_DEVICES];              // per device id; 0 = not queried yet
+    int& c = cus[sisr_device_index()];
+    if (c == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            c = v;
+        else
+            c = 256;
+    }
+    int n = c;
+    if (const char* e = getenv("SISR_PERSIST_MAX_WG")) {
+        const int cap = atoi(e);
+        if (cap > 0 && cap < n) n = cap;
+    }
+    return n;
 }
 
 extern "C" int sisr_device_info(int32_t* n_cu, int32_t* lds_per_cu, char* arch, int32_t arch_len) {

@@ -16,6 +16,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         if (e__ != hipSuccess) return (int)e__;      \
     } while (0)
 
+// ---- host side: per-device state ------------------------------------------------------------------------------------
+// One process normally drives one GPU (one rank per device), but nothing below assumes it: the CU count and the
+// dynamic-LDS caps are kept per device id, so a host that switches devices (the reference's nn.DataParallel,
+// config.py:114-118) gets correct grids and attributes on each.
+#define SISR_MAX_DEVICES 64
+int sisr_device_index();                   // misc.hip: current device id, clamped to [0, SISR_MAX_DEVICES)
+// misc.hip: workgroup slots a persistent kernel may fill = CUs of the CURRENT device.  SISR_PERSIST_MAX_WG=<n> caps it
+// (test knob: a small cap makes a small input walk many tiles per workgroup, the schedule of the full-size launches)
+int sisr_cu_slots();
+struct SisrLdsCap { int v[SISR_MAX_DEVICES]; };
+// raise hipFuncAttributeMaxDynamicSharedMemorySize of `fn` on the current device when `bytes` exceeds what was set
+// (`base`: the cap a kernel starts with -- 64 KB without the attribute, 0 forces the first call to set it)
+static inline int sisr_raise_lds_cap(SisrLdsCap& cap, const void* fn, int bytes, int base = 0) {
+    int& cur = cap.v[sisr_device_index()];
+    if (cur < base) cur = base;
+    if (bytes <= cur) return 0;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    cur = bytes;
+    return 0;
+}
+
 // leaky-relu family: PReLU (shared slope), LeakyReLU(0.01), ReLU (slope 0), identity (slope 1)
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
 

@@ -261,13 +261,8 @@ extern "C" int sisr_wgrad_plan_bf16(SisrWgradDesc* d, int32_t max_pixel_blocks) 
 
 template <int TPW>
 static int launch_wgrad_bf16(const SisrWgradDesc* d, hipStream_t st) {
-    static int lds_max = 64 * 1024;
-    if (d->lds_bytes > lds_max) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_bf16_kernel<TPW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, d->lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        lds_max = d->lds_bytes;
-    }
+    static SisrLdsCap cap;
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&wgrad_mfma_bf16_kernel<TPW>), d->lds_bytes, 64 * 1024)) return e;
     const dim3 grid(d->grid_x, d->n_chunk * (d->CoutPad / (d->NJ * 32)));
     hipLaunchKernelGGL(wgrad_mfma_bf16_kernel<TPW>, grid, dim3(SISR_BLOCK), d->lds_bytes, st, *d);
     SISR_CHECK_LAUNCH();

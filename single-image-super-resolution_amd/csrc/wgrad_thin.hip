@@ -207,16 +207,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_thin_kernel(const WThinArgs a) {
     }
 }
 
-static int wn_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
-        cus = pr.multiProcessorCount;
-    }
-    return cus;
-}
+static int wn_cus() { return sisr_cu_slots(); }
 
 extern "C" int sisr_wgrad_thin_eligible(const SisrWgradDesc* d) {
     const char* sw = getenv("SISR_THIN");                       // A/B switch: SISR_THIN=0 keeps the generic kernel
@@ -242,16 +233,9 @@ int sisr_wgrad_thin_launch(const SisrWgradDesc* d, hipStream_t st) {
     constexpr int lds_bytes = WN_XBYTES + WN_DBYTES;
     const bool actb = d->gpro_mode == SISR_PRO_ACT_BWD;
     if (actb && !d->g2) return SISR_E_BADARG;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_thin_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_thin_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static SisrLdsCap cap_t, cap_f;
+    if (int e = sisr_raise_lds_cap(cap_t, reinterpret_cast<const void*>(&wgrad_thin_kernel<true>), lds_bytes)) return e;
+    if (int e = sisr_raise_lds_cap(cap_f, reinterpret_cast<const void*>(&wgrad_thin_kernel<false>), lds_bytes)) return e;
     WThinArgs a;
     a.x = d->x1; a.g1 = d->g1; a.g2 = d->g2; a.slab = d->slab; a.bias_slab = d->bias_slab;
     a.slope_p = d->gpro_slope_p; a.slope = d->gpro_slope;

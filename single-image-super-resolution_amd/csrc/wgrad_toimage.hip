@@ -199,16 +199,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_toimage_kernel(const WToImageArg
     }
 }
 
-static int wi_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
-        cus = pr.multiProcessorCount;
-    }
-    return cus;
-}
+static int wi_cus() { return sisr_cu_slots(); }
 
 extern "C" int sisr_wgrad_toimage_eligible(const SisrWgradDesc* d) {
     const char* sw = getenv("SISR_THIN");                       // A/B switch: SISR_THIN=0 keeps the generic kernel
@@ -234,13 +225,8 @@ int sisr_wgrad_toimage_slabs(const SisrWgradDesc* d) { return wi_grid(d); }
 template <bool ACT, bool TANHB>
 static int wi_launch(const WToImageArgs& a, int grid, hipStream_t st) {
     constexpr int lds_bytes = WI_XBYTES + WI_GBYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_toimage_kernel<ACT, TANHB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static SisrLdsCap cap;
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&wgrad_toimage_kernel<ACT, TANHB>), lds_bytes)) return e;
     hipLaunchKernelGGL((wgrad_toimage_kernel<ACT, TANHB>), dim3(grid), dim3(256), lds_bytes, st, a);
     SISR_CHECK_LAUNCH();
     return 0;
@@ -433,13 +419,8 @@ extern "C" int sisr_wgrad_toimage_f32_eligible(const SisrWgradDesc* d) {
 template <bool ACT, bool TANHB>
 static int wj_launch(const WToImageF32Args& a, int grid, hipStream_t st) {
     constexpr int lds_bytes = WJ_XBYTES + WJ_GBYTES + 256;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_toimage_f32_kernel<ACT, TANHB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static SisrLdsCap cap;
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&wgrad_toimage_f32_kernel<ACT, TANHB>), lds_bytes)) return e;
     hipLaunchKernelGGL((wgrad_toimage_f32_kernel<ACT, TANHB>), dim3(grid), dim3(256), lds_bytes, st, a);
     SISR_CHECK_LAUNCH();
     return 0;

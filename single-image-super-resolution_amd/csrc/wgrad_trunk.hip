@@ -351,14 +351,7 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
 // ---- host ----------------------------------------------------------------------------------------------------------
 static int wtrunk_grid(const SisrWgradDesc* d) {
     const int total = d->N * (d->H / WT_TH) * (d->W / WT_TW);
-    static int cus = 0;                         // (one process drives one GPU: queried once)
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-        else
-            cus = 256;
-    }
+    const int cus = sisr_cu_slots();
     const int G = d->Cout == 256 ? 4 : 1;       // cout groups: each tile stream is served by G workgroups
     const int slots = std::max(1, cus / G);
     const int rounds = (total + slots - 1) / slots;
@@ -400,13 +393,8 @@ extern "C" int sisr_wgrad_bf16_slabs(const SisrWgradDesc* d) {
 template <int GPRO>
 static int launch_wtrunk(const WTrunkArgs& a, int grid, hipStream_t st) {
     constexpr int lds_bytes = 2 * (WT_XBYTES + WT_DBYTES) + 2 * 64 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_trunk_kernel<GPRO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static SisrLdsCap cap;
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&wgrad_trunk_kernel<GPRO>), lds_bytes)) return e;
     hipLaunchKernelGGL((wgrad_trunk_kernel<GPRO>), dim3(grid), dim3(WT_THREADS), lds_bytes, st, a);
     SISR_CHECK_LAUNCH();
     return 0;

@@ -219,14 +219,7 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
 // ---- host ----------------------------------------------------------------------------------------------------------
 static int wf_grid(const SisrWgradDesc* d) {
     const int total = d->N * (d->H / WF_TH) * (d->W / WF_TW);
-    static int cus = 0;                         // (one process drives one GPU: queried once)
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-        else
-            cus = 256;
-    }
+    const int cus = sisr_cu_slots();
     const int rounds = (total + cus - 1) / cus;
     return (total + rounds - 1) / rounds;       // equal shares
 }
@@ -263,13 +256,8 @@ extern "C" int sisr_wgrad_f32_slabs(const SisrWgradDesc* d) {
 template <int GPRO>
 static int launch_wf(const WTrunkF32Args& a, int grid, hipStream_t st) {
     constexpr int lds_bytes = 2 * (WF_XBYTES + WF_DBYTES);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_trunk_f32_kernel<GPRO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static SisrLdsCap cap;
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&wgrad_trunk_f32_kernel<GPRO>), lds_bytes)) return e;
     hipLaunchKernelGGL((wgrad_trunk_f32_kernel<GPRO>), dim3(grid), dim3(WF_THREADS), lds_bytes, st, a);
     SISR_CHECK_LAUNCH();
     return 0;

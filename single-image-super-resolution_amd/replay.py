@@ -12,6 +12,20 @@ presenting it costs nothing.  Set ``dis_list_old_cpu = False`` (config.py:53) an
 
 The sampling (train.py:144-145) and the overwrite policy (train.py:66-71) draw from the same host generators as the
 reference (``numpy.random.choice`` / ``random.randint``), so a seeded run picks the same entries.
+
+Two properties of the reference's plain list that the ring must not lose:
+
+* **Assignment rebinds, it never mutates.**  train.py runs the D forwards on the sampled entries (train.py:64), THEN
+  assigns ``dis_list_old[randint] = curr_fake`` (train.py:68-69), THEN calls ``errD.backward()`` (train.py:74).  The
+  discriminator's backward reads its saved inputs, so copying into a ring slot at assignment time would hand the
+  weight gradient of the first conv the NEW batch whenever the overwritten slot was one of those just sampled.  An
+  assignment into a held slot is therefore only RECORDED; the device copy happens at the next READ access of the list
+  (sample / index / iterate / append / save), i.e. in the next iteration, after the backward pass that may still read
+  the old contents.  ``flush()`` forces it.
+* **The checkpoint holds a plain list.**  utils.py:108-115 pickles the object it was given as ``'dis_list'``;
+  ``__reduce__`` makes that a Python list of the held batches as CPU tensors -- the reference's own format, readable
+  without this package (``torch.load(..., weights_only=True)`` additionally needs
+  ``torch.serialization.add_safe_globals([list])``: a reduced list is a call of ``builtins.list``).
 """
 import random
 
@@ -26,41 +40,59 @@ class DeviceReplayList:
         self.capacity, self.device, self.dtype = int(capacity), device, dtype
         self._ring = None             # allocated at the first append (the batch shape is not known before)
         self._n = 0
+        self._pending = {}            # slot -> batch: assignments recorded but not copied yet (see module docstring)
+
+    def flush(self):
+        """apply the recorded assignments (one device copy each)"""
+        if self._pending:
+            todo, self._pending = self._pending, {}
+            for i, batch in todo.items():
+                self._ring[i].copy_(batch, non_blocking=True)
 
     # ---- list protocol (what train.py:66-71,144-156 and utils.py:114 use) ------------------------------------------
     def __len__(self):
         return self._n
 
-    def _slot(self, i):
+    def _index(self, i):
+        i = int(i)
         if not -self._n <= i < self._n:
             raise IndexError('replay list index out of range')
-        return self._ring[i % self._n if i < 0 else i]
+        return i % self._n if i < 0 else i
 
     def __getitem__(self, i):
+        self.flush()
         if isinstance(i, slice):
-            return [self._slot(k) for k in range(*i.indices(self._n))]
-        return self._slot(int(i))
+            return [self._ring[k] for k in range(*i.indices(self._n))]
+        return self._ring[self._index(i)]
 
     def __setitem__(self, i, batch):
-        self._slot(int(i)).copy_(batch, non_blocking=True)
+        i = self._index(i)
+        self._check_shape(batch)
+        self._pending[i] = batch.detach()              # (a second assignment to the same slot replaces the first)
 
     def __iter__(self):
+        self.flush()
         return (self._ring[k] for k in range(self._n))
+
+    def _check_shape(self, batch):
+        if self._ring is not None and tuple(batch.shape) != tuple(self._ring.shape[1:]):
+            raise ValueError('replay list holds batches of shape %s, got %s' % (tuple(self._ring.shape[1:]), tuple(batch.shape)))
 
     def append(self, batch):
         if self._ring is None:
             dev = self.device if self.device is not None else batch.device
             self._ring = torch.empty((self.capacity,) + tuple(batch.shape), dtype=self.dtype, device=dev)
-        if tuple(batch.shape) != tuple(self._ring.shape[1:]):
-            raise ValueError('replay list holds batches of shape %s, got %s' % (tuple(self._ring.shape[1:]), tuple(batch.shape)))
+        self._check_shape(batch)
         if self._n == self.capacity:
             raise IndexError('replay list is full (%d entries): overwrite an entry instead (train.py:68-69)' % self.capacity)
-        self._ring[self._n].copy_(batch, non_blocking=True)
+        self.flush()
+        self._ring[self._n].copy_(batch, non_blocking=True)      # (a slot nobody has seen yet: nothing can be reading it)
         self._n += 1
 
     # ---- the reference's policies ------------------------------------------------------------------------------------
     def sample(self, ratio):
         """train.py:144-145: ``int(len * ratio)`` distinct entries, drawn with numpy's global generator"""
+        self.flush()
         idx = np.random.choice(list(range(self._n)), int(self._n * ratio), replace=False)
         return [self._ring[int(i)] for i in idx]
 
@@ -75,7 +107,14 @@ class DeviceReplayList:
 
     # ---- checkpoint interchange (utils.py:108-115 saves the list as 'dis_list') ---------------------------------------
     def to_list(self):
-        return [self._ring[k].detach().cpu() for k in range(self._n)]
+        self.flush()
+        # (own storage per entry: a view of a host-resident ring would drag the whole ring into torch.save)
+        return [self._ring[k].detach().to('cpu', copy=True) for k in range(self._n)]
+
+    def __reduce__(self):
+        """pickled (torch.save of utils.py:108-115) as a plain list of the held batches on the CPU: the reference's own
+        checkpoint format, not this class and not the preallocated ring"""
+        return (list, (self.to_list(),))
 
     @classmethod
     def from_list(cls, batches, capacity, device):

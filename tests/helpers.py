@@ -56,15 +56,35 @@ def oracle_fwd_bwd(cfg, state, x, r, training=True):
     return out.detach(), x.grad, grads, new
 
 
+def analytically_zero(key, ref):
+    """parameter gradients that are exactly zero in exact arithmetic: the bias of a conv whose output goes straight
+    into a training-mode BatchNorm (generator: block_list.*.layers.{0,3}.bias, block_list_end.0.bias; discriminator:
+    conv.2.*.layers.0.bias) -- the mean subtraction removes any constant, so both sides hold rounding noise only.
+    Told from the key layout of the gradient dict: `<p>.<i>.bias` is such a bias when `<p>.<i+1>` is a BatchNorm
+    (a 1-D `.weight` and a `.bias` of the same length > 1; a PReLU has a 1-element weight and no bias)."""
+    if not key.endswith('.bias'):
+        return False
+    head, _, idx = key[:-len('.bias')].rpartition('.')
+    if not idx.isdigit():
+        return False
+    nxt = '%s.%d' % (head, int(idx) + 1)
+    w, b = ref.get(nxt + '.weight'), ref.get(nxt + '.bias')
+    return w is not None and b is not None and w.dim() == 1 and w.numel() > 1 and w.numel() == ref[key].numel()
+
+
 def grads_close(got, ref, tol, floor=0.02):
-    """Per-tensor max|got-ref| <= tol * max(|ref|_inf, floor*G), G = largest grad magnitude in
-    the model.  The floor exists for gradients that are analytically ZERO (a conv bias feeding a
-    training-mode BatchNorm): there both sides hold only rounding noise of size ~eps*sum|dy|."""
+    """Per-tensor max|got-ref| <= tol * |ref|_inf  -- BASELINE.json's '1e-3 relative fp32', tensor by tensor.
+    Only the gradients that are analytically ZERO (analytically_zero()) are held to an absolute bound instead,
+    tol * floor * G with G the largest gradient magnitude of the model: there both sides hold only rounding noise of
+    size ~eps * sum|dy|."""
     big = max(float(v.abs().max()) for v in ref.values())
     bad = []
     for k, b in ref.items():
         a = got[k]
-        scale = max(float(b.abs().max()), floor * big)
+        if analytically_zero(k, ref):
+            scale = max(float(b.abs().max()), floor * big)
+        else:
+            scale = max(float(b.abs().max()), 1e-30)
         err = float((a.double() - b.double()).abs().max()) / scale
         if not err < tol:
             bad.append((k, err))

@@ -222,6 +222,19 @@ def test_bicubic_against_golden(L, golden_dir):
 
 
 # ---- bf16 matrix-core kernel family (fp32 tensors in HBM, bf16 MFMA, fp32 accumulate) -------------------
+def _walk(shape, monkeypatch):
+    """shape = (n, h, w) or (n, h, w, cap).  cap: SISR_PERSIST_MAX_WG, the number of workgroup slots the persistent
+    kernels may fill -- with a small cap a small input walks SEVERAL tiles per workgroup (double-buffer swap, T+2
+    prefetch, statistics / reductions / weight gradient carried across tiles), the schedule the B16 96x96 launches of
+    the benchmark run; the (16, 96, 96) / (16, 192, 192) entries are those launches themselves (1,152 tiles)."""
+    if len(shape) == 4:
+        monkeypatch.setenv('SISR_PERSIST_MAX_WG', str(shape[3]))
+    return shape[:3]
+
+
+TRUNK_SHAPES = [(2, 16, 32), (3, 24, 48), (1, 96, 96), (3, 24, 48, 5), (16, 96, 96)]
+TRUNK_SHAPES_SHORT = [(2, 16, 32), (1, 96, 96), (3, 24, 48, 5), (16, 96, 96)]
+
 BF16_TOL = 2e-2      # bf16 has 8 significant bits: operands rounded to 2^-9 relative, fp32 accumulation
 
 
@@ -363,12 +376,12 @@ def _merged_stats(sp, cp):
 
 
 @pytest.mark.parametrize('pro', ['none', 'act', 'affine_act'])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 48), (1, 96, 96)])
+@pytest.mark.parametrize('shape', TRUNK_SHAPES)
 def test_trunk_kernel_matches_the_generic_kernel_and_the_reference(E, L, shape, pro, monkeypatch):
     """conv_trunk.hip (persistent, weights in registers; 3x3 64->64 on bf16 tensors, H % 8 == 0, W % 16 == 0) against
     the generic bf16 kernel on the same operands and against F.conv2d: output, and the BatchNorm statistics merged from
     its per-workgroup partials"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     monkeypatch.setenv('SISR_STORAGE', 'bf16')
     x = (_rand((n, 64, h, w), 61) * 2.0).bfloat16().float()
     wt = _rand((64, 64, 3, 3), 62, (1.0 / 576) ** 0.5 * 1.7)
@@ -412,12 +425,12 @@ def test_trunk_kernel_matches_the_generic_kernel_and_the_reference(E, L, shape, 
 
 @pytest.mark.parametrize('pro,res,bnb', [('bnbwd', False, None), ('bnbwd', True, 'plain'), ('bnact_bwd', True, 'act'),
                                          ('bnact_bwd', False, 'plain'), ('bnact_bwd', True, None), ('bnbwd', False, 'act')])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 48), (1, 96, 96)])
+@pytest.mark.parametrize('shape', TRUNK_SHAPES)
 def test_trunk_kernel_data_gradient_role(E, L, shape, pro, res, bnb, monkeypatch):
     """conv_trunk.hip, data-gradient role: two-tensor BatchNorm-backward prologue (with / without the activation),
     skip gradient added in the epilogue, backward reductions of the next BatchNorm from the epilogue -- against the
     generic bf16 kernel on the same operands and against conv_transpose2d of the prologue written out in fp32"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     monkeypatch.setenv('SISR_STORAGE', 'bf16')
     bf = lambda t: t.bfloat16().float()
     g_in, c = bf(_rand((n, 64, h, w), 71)), bf(_rand((n, 64, h, w), 72) * 2.0)
@@ -473,12 +486,12 @@ def test_trunk_kernel_data_gradient_role(E, L, shape, pro, res, bnb, monkeypatch
 
 
 @pytest.mark.parametrize('xpro,gpro', [('none', 'bnbwd'), ('act', 'bnact_bwd'), ('affine_act', 'bnbwd'), ('affine_act', 'bnact_bwd')])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 48), (1, 96, 96)])
+@pytest.mark.parametrize('shape', TRUNK_SHAPES)
 def test_trunk_kernel_weight_gradient_role(E, L, shape, xpro, gpro, monkeypatch):
     """wgrad_trunk.hip (persistent, the whole 64 x 576 gradient in accumulators, one slab per workgroup) against the
     generic bf16 weight-gradient kernel on the same lazy operands and against autograd on the prologues written out in
     fp32: packed gradient, un-packed weight gradient, bias gradient"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     monkeypatch.setenv('SISR_STORAGE', 'bf16')
     bf = lambda t: t.bfloat16().float()
     bc = lambda v: v[None, :, None, None]
@@ -535,12 +548,12 @@ def test_trunk_kernel_weight_gradient_role(E, L, shape, xpro, gpro, monkeypatch)
 
 
 @pytest.mark.parametrize('xpro,gpro', [('none', 'bnbwd'), ('act', 'bnact_bwd'), ('affine_act', 'bnbwd'), ('affine_act', 'bnact_bwd')])
-@pytest.mark.parametrize('shape', [(2, 12, 16), (3, 24, 48), (1, 96, 96)])
+@pytest.mark.parametrize('shape', [(2, 12, 16)] + TRUNK_SHAPES[1:])
 def test_trunk_kernel_weight_gradient_role_fp32(E, L, shape, xpro, gpro, monkeypatch):
     """wgrad_trunk_f32.hip (parity build: fp32 tensors, exact fp32 MFMA, persistent accumulators, 4 x 16 tiles) against
     the generic fp32 weight-gradient kernel on the same lazy operands and against autograd: packed gradient, un-packed
     weight gradient, bias gradient, bit-identical replay"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     bc = lambda v: v[None, :, None, None]
     x = _rand((n, 64, h, w), 111) * 2.0
     g_in, c = _rand((n, 64, h, w), 112), _rand((n, 64, h, w), 113) * 2.0
@@ -597,12 +610,12 @@ def test_trunk_kernel_weight_gradient_role_fp32(E, L, shape, xpro, gpro, monkeyp
 
 
 @pytest.mark.parametrize('pro', ['none', 'act', 'affine_act'])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 48), (1, 96, 96)])
+@pytest.mark.parametrize('shape', TRUNK_SHAPES)
 def test_trunk_kernel_fp32_forward_role(E, L, shape, pro, monkeypatch):
     """conv_trunk_f32.hip (parity build: fp32 tensors, exact fp32 MFMA, weights of one cout half resident in LDS, producer /
     consumer waves), forward role, against the generic fp32 kernel on the same operands and against F.conv2d in double:
     output and the BatchNorm statistics merged from its per-stream partial rows"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     x = _rand((n, 64, h, w), 131) * 2.0
     wt = _rand((64, 64, 3, 3), 132, (1.0 / 576) ** 0.5 * 1.7)
     b = _rand((64,), 133, 0.1)
@@ -644,11 +657,11 @@ def test_trunk_kernel_fp32_forward_role(E, L, shape, pro, monkeypatch):
 
 
 @pytest.mark.parametrize('pro,res', [('bnbwd', False), ('bnbwd', True), ('bnact_bwd', True), ('bnact_bwd', False)])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 48), (1, 96, 96)])
+@pytest.mark.parametrize('shape', TRUNK_SHAPES)
 def test_trunk_kernel_fp32_data_gradient_role(E, L, shape, pro, res, monkeypatch):
     """conv_trunk_f32.hip, data-gradient role: two-tensor BatchNorm-backward prologue (with / without the activation),
     skip gradient added in the epilogue -- against the generic fp32 kernel and against conv_transpose2d in double"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     g_in, c = _rand((n, 64, h, w), 141), _rand((n, 64, h, w), 142) * 2.0
     wt = _rand((64, 64, 3, 3), 143, (1.0 / 576) ** 0.5 * 1.7)
     qa, qb, qd = _rand((64,), 144) * 0.3 + 1.0, _rand((64,), 145) * 0.2, _rand((64,), 146) * 0.1
@@ -679,11 +692,11 @@ def test_trunk_kernel_fp32_data_gradient_role(E, L, shape, pro, res, monkeypatch
 
 
 @pytest.mark.parametrize('pro,res,act', [('bnbwd', True, False), ('bnact_bwd', True, True), ('bnbwd', False, True)])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (1, 96, 96)])
+@pytest.mark.parametrize('shape', TRUNK_SHAPES_SHORT)
 def test_trunk_kernel_fp32_fused_bn_backward_reductions(E, L, shape, pro, res, act, monkeypatch):
     """conv_trunk_f32.hip, data-gradient role with bnb: the epilogue's per-workgroup rows of the next BatchNorm's backward
     reductions, finalized, must equal the stand-alone reduction over the same gradient (fp32: 1e-5)"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     g_in, c = _rand((n, 64, h, w), 151), _rand((n, 64, h, w), 152) * 2.0
     wt = _rand((64, 64, 3, 3), 153, (1.0 / 576) ** 0.5 * 1.7)
     qa, qb, qd = _rand((64,), 154) * 0.3 + 1.0, _rand((64,), 155) * 0.2, _rand((64,), 156) * 0.1
@@ -722,12 +735,12 @@ def test_trunk_kernel_fp32_fused_bn_backward_reductions(E, L, shape, pro, res, a
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 @pytest.mark.parametrize('res_slope', [None, 0.25])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (1, 96, 96)])
+@pytest.mark.parametrize('shape', TRUNK_SHAPES_SHORT)
 def test_trunk_kernels_form_the_skip_sum_in_their_staging(E, L, shape, res_slope, precision, monkeypatch):
     """SISR_PRO_RES_AFFINE (both persistent forward kernels): conv(lrelu(res) + (scale * t + shift)) with the sum stored
     once as a side effect -- against the separate elementwise pass followed by the plain conv: the materialised sum must be
     bit-identical (same fp32 expression, same rounding), the conv output equal up to summation order, statistics equal"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     if precision == 'bf16':
         monkeypatch.setenv('SISR_STORAGE', 'bf16')
     E.set_precision(precision)
@@ -756,12 +769,12 @@ def test_trunk_kernels_form_the_skip_sum_in_their_staging(E, L, shape, res_slope
 
 
 @pytest.mark.parametrize('pro', ['none', 'act'])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (1, 96, 96)])
+@pytest.mark.parametrize('shape', TRUNK_SHAPES_SHORT)
 def test_trunk_kernel_upscale_conv_with_pixel_shuffle_store(E, L, shape, pro, monkeypatch):
     """conv_trunk.hip forward role with Cout = 256 stored through PixelShuffle(2) (the generator's upscale conv,
     model_generator.py:43-48: four cout groups = the four shuffle phases) against the generic bf16 kernel and against
     F.pixel_shuffle(F.conv2d(...)) -- bias in original channel order included"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     monkeypatch.setenv('SISR_STORAGE', 'bf16')
     x = (_rand((n, 64, h, w), 181) * 2.0).bfloat16().float()
     wt = _rand((256, 64, 3, 3), 182, (1.0 / 576) ** 0.5 * 1.7)
@@ -786,12 +799,12 @@ def test_trunk_kernel_upscale_conv_with_pixel_shuffle_store(E, L, shape, pro, mo
         E.set_precision('fp32')
 
 
-@pytest.mark.parametrize('shape', [(2, 16, 32), (1, 96, 96)])
+@pytest.mark.parametrize('shape', TRUNK_SHAPES_SHORT)
 def test_trunk_kernel_upscale_conv_weight_gradient(E, L, shape, monkeypatch):
     """wgrad_trunk.hip with Cout = 256 and the gradient stored shuffled (the upscale conv: four cout groups = the four
     PixelShuffle phases, activation-backward prologue on the strided view of each phase) against the generic bf16 kernel
     and against autograd through conv -> pixel_shuffle -> PReLU"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     monkeypatch.setenv('SISR_STORAGE', 'bf16')
     bf = lambda t: t.bfloat16().float()
     x = bf(_rand((n, 64, h, w), 191) * 2.0)
@@ -827,13 +840,13 @@ def test_trunk_kernel_upscale_conv_weight_gradient(E, L, shape, monkeypatch):
 
 
 @pytest.mark.parametrize('role', ['first_conv', 'end_dgrad'])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 48, 48), (1, 96, 96)])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 48, 48), (1, 96, 96), (3, 48, 48, 4), (16, 96, 96), (4, 192, 192)])
 def test_thin_kernel_over_a_3_channel_image(E, L, shape, role, monkeypatch):
     """conv_thin.hip -- the generator's first conv (model_generator.py:32: 9x9, NCHW fp32 image -> 64 bf16 NHWC channels)
     and the data gradient of its last conv (model_generator.py:52-53: 3x3 over the 3-channel image gradient with tanh'
     as prologue and the flipped weights) -- against the generic kernel the same descriptor runs on with SISR_THIN=0 and
     against F.conv2d / autograd on the bf16-rounded operands"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     monkeypatch.setenv('SISR_STORAGE', 'bf16')
     bf = lambda t: t.bfloat16().float()
     E.set_precision('bf16')
@@ -877,12 +890,12 @@ def test_thin_kernel_over_a_3_channel_image(E, L, shape, role, monkeypatch):
 
 
 @pytest.mark.parametrize('act', [True, False])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 64), (1, 96, 96)])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 64), (1, 96, 96), (3, 24, 64, 3), (16, 96, 96)])
 def test_thin_kernel_first_conv_weight_gradient(E, L, shape, act, monkeypatch):
     """wgrad_thin.hip -- weight / bias gradient of the generator's first conv (model_generator.py:32-33: 9x9 over the
     NCHW fp32 image; the gradient arrives through the PReLU, activation-backward prologue) -- against the generic
     exact-fp32 kernel the same descriptor runs on with SISR_THIN=0 and against autograd"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     monkeypatch.setenv('SISR_STORAGE', 'bf16')
     bf = lambda t: t.bfloat16().float()
     x = _rand((n, 3, h, w), 221)
@@ -923,12 +936,12 @@ def test_thin_kernel_first_conv_weight_gradient(E, L, shape, act, monkeypatch):
 
 
 @pytest.mark.parametrize('pro,tanh', [('act', True), ('none', True), ('act', False)])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 13, 31), (1, 96, 96), (2, 192, 192)])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 13, 31), (1, 96, 96), (2, 192, 192), (16, 192, 192)])
 def test_last_conv_as_gemm_plus_col2im(E, L, shape, pro, tanh, monkeypatch):
     """conv_toimage.hip -- the generator's last conv (model_generator.py:52-53: 3x3, 64 -> 3, + Tanh; bf16 NHWC
     activations in, NCHW fp32 image out; PReLU of the upscale stage as prologue) -- against the generic bf16 kernel the
     same descriptor runs on with SISR_THIN=0 and against F.conv2d on the bf16-rounded operands; ragged sizes included"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     monkeypatch.setenv('SISR_STORAGE', 'bf16')
     bf = lambda t: t.bfloat16().float()
     x = bf(_rand((n, 64, h, w), 231) * 2.0)
@@ -958,12 +971,12 @@ def test_last_conv_as_gemm_plus_col2im(E, L, shape, pro, tanh, monkeypatch):
 
 
 @pytest.mark.parametrize('pro,tanh', [('act', True), ('none', False)])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 64), (1, 96, 96)])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 64), (1, 96, 96), (3, 24, 64, 3), (16, 192, 192)])
 def test_last_conv_weight_gradient_reads_the_image_gradient_directly(E, L, shape, pro, tanh, monkeypatch):
     """wgrad_toimage.hip -- weight / bias gradient of the generator's last conv (model_generator.py:52-53: 3x3, 64 -> 3,
     + Tanh; bf16 NHWC activations through the PReLU prologue, NCHW fp32 image gradient through tanh') -- against the
     generic bf16 kernel (which runs on a 4-channel NHWC copy of the gradient, SISR_THIN=0) and against autograd"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     monkeypatch.setenv('SISR_STORAGE', 'bf16')
     bf = lambda t: t.bfloat16().float()
     x = bf(_rand((n, 64, h, w), 241) * 2.0)
@@ -1005,11 +1018,11 @@ def test_last_conv_weight_gradient_reads_the_image_gradient_directly(E, L, shape
 
 
 @pytest.mark.parametrize('pro,tanh', [('act', True), ('none', False)])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 13, 31), (1, 96, 96)])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 13, 31), (1, 96, 96), (16, 192, 192)])
 def test_last_conv_as_gemm_plus_col2im_fp32(E, L, shape, pro, tanh, monkeypatch):
     """conv_toimage.hip's exact-fp32 variant (fp32 parity build: fp32 NHWC activations in, NCHW fp32 image out) against
     the generic fp32 kernel (SISR_THIN=0) and F.conv2d at the parity build's tolerance"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     x = _rand((n, 64, h, w), 251) * 2.0
     wt = _rand((3, 64, 3, 3), 252, (1.0 / 576) ** 0.5 * 1.7)
     b = _rand((3,), 253, 0.1)
@@ -1031,11 +1044,11 @@ def test_last_conv_as_gemm_plus_col2im_fp32(E, L, shape, pro, tanh, monkeypatch)
 
 
 @pytest.mark.parametrize('pro,tanh', [('act', True), ('none', False)])
-@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 64), (1, 96, 96)])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 64), (1, 96, 96), (3, 24, 64, 3), (16, 192, 192)])
 def test_last_conv_weight_gradient_fp32(E, L, shape, pro, tanh, monkeypatch):
     """wgrad_toimage.hip's exact-fp32 variant (fp32 parity build) against the generic fp32 kernel (SISR_THIN=0) and
     autograd at the parity build's tolerance; padding entries of the packed slab are zero"""
-    n, h, w = shape
+    n, h, w = _walk(shape, monkeypatch)
     x = _rand((n, 64, h, w), 261) * 2.0
     wt = _rand((3, 64, 3, 3), 262, (1.0 / 576) ** 0.5 * 1.7)
     b = _rand((3,), 263, 0.1)

@@ -146,6 +146,53 @@ def test_d_step_with_on_device_experience_replay_matches_oracle():
     assert len(lst) == 4 and torch.equal(lst[3].cpu(), curr)
 
 
+def test_overwriting_a_sampled_replay_entry_between_forward_and_backward():
+    """train.py:64-74 with a FULL list: adversarial_loss_d runs D on the sampled old fakes, then
+    `dis_list_old[randint] = curr_fake` overwrites one of them, then errD.backward().  The discriminator engine keeps
+    its input by reference, so a ring that copied at assignment time would compute the first conv's weight gradient
+    from the new batch; the reference's list only rebinds the entry.  D's gradients must equal the oracle's (which
+    never sees the overwrite), and the list must hold the new batch afterwards."""
+    import numpy as np
+    from oracle import models as om, losses as ol
+    md, rp = pkg('model_discriminator'), pkg('replay')
+    torch.manual_seed(0)
+    net_d = md.Discriminator((3, 32, 32), FEATS, STRIDES)
+    d_state = {k: v.detach().clone() for k, v in net_d.state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    real = torch.rand(8, 3, 32, 32, generator=g) * 2 - 1
+    curr = torch.rand(8, 3, 32, 32, generator=g) * 2 - 1
+    olds = [torch.rand(8, 3, 32, 32, generator=g) * 2 - 1 for _ in range(3)]
+    st = {k: v.clone() for k, v in d_state.items()}
+    for k in om.param_keys(st):
+        st[k].requires_grad_(True)
+    np.random.seed(4)
+    picked = ol.replay_sample_indices(3, 1.0)                     # every entry is presented to D
+    d_real, new = om.discriminator_forward(st, real, STRIDES, True)
+    st.update(new)
+    d_fakes = []
+    for fk in [curr] + [olds[i] for i in picked]:
+        d_f, new = om.discriminator_forward(st, fk, STRIDES, True)
+        st.update(new)
+        d_fakes.append(d_f)
+    ol.adversarial_loss_d(d_real, d_fakes).backward()
+    grads_ref = {k: st[k].grad for k in om.param_keys(st)}
+    dev = torch.device('cuda')
+    net_d = net_d.to(dev).train()
+    lst = rp.DeviceReplayList(3, dev)                             # full: the next store overwrites
+    for o in olds:
+        lst.append(o.to(dev))
+    np.random.seed(4)
+    net_d.zero_grad()
+    _, _, err = rp.adversarial_loss_d(net_d, torch.nn.BCELoss(), real.to(dev), curr.to(dev), lst,
+                                      torch.full((8,), .9, device=dev), torch.zeros(8, device=dev), 1.0)
+    for k in range(3):
+        lst[k] = curr.to(dev) * float(k + 2)                      # train.py:68-69, on every slot D has just read
+    err.backward()                                                # train.py:74
+    got = {k: p.grad.detach().cpu() for k, p in net_d.named_parameters()}
+    assert grads_close(got, grads_ref, TOL) == []
+    assert torch.equal(lst[2].cpu(), curr * 4.0) and torch.equal(lst[0].cpu(), curr * 2.0)
+
+
 def test_unsupervised_branch_content_loss_on_lr_matches_oracle():
     """row f4: the `content_loss_on_lr` G step (train.py:95-97, config.py:24,128-130,152-161): the generated image is
     degraded again with the DIFFERENTIABLE lr_from_hr and compared with the LR input through the identity extractor,

@@ -31,7 +31,7 @@ def test_store_and_overwrite_policy_matches_the_reference_list():
     assert all(torch.equal(a, b) for a, b in zip(lst, ref))
     base = lst._ring.data_ptr()
     assert [e.data_ptr() for e in lst] == [base + k * bs[0].numel() * 4 for k in range(3)]     # views of one ring
-    lst[1] = bs[0]                                                   # list assignment = device copy into the slot
+    lst[1] = bs[0]                                                   # list assignment = (deferred) device copy into the slot
     assert torch.equal(lst[1], bs[0]) and lst[1].data_ptr() == base + bs[0].numel() * 4
     assert torch.equal(lst[-1], ref[-1])
 
@@ -57,3 +57,61 @@ def test_checkpoint_round_trip_and_size_rule():
     again = R.gen_dis_list(saved, 5, 'cpu', progressive_gan_suffix=2)
     assert len(again) == 4 and all(torch.equal(a, b) for a, b in zip(again, bs))
     assert len(R.gen_dis_list(saved, 5, 'cpu', progressive_gan_suffix=1)) == 0       # config.py:325-330: size changed
+
+
+def test_assignment_does_not_touch_a_sampled_entry_until_the_next_access():
+    """train.py:64-74: D forward on the sampled entries, THEN `dis_list_old[k] = curr_fake`, THEN backward.  The
+    reference's assignment rebinds the list entry and leaves the tensor autograd saved alone; the ring must do the same:
+    the sampled view keeps its contents until the list is accessed again (the next iteration)."""
+    bs = _batches(4)
+    lst = R.DeviceReplayList(3, device='cpu')
+    for b in bs[:3]:
+        lst.append(b)
+    np.random.seed(1)
+    sampled = lst.sample(1.0)                                        # views of all three slots, as D's forward sees them
+    before = [t.clone() for t in sampled]
+    order = [int(i) for i in np.random.RandomState(1).choice(list(range(3)), 3, replace=False)]
+    lst[order[0]] = bs[3]                                            # overwrite a slot that was just sampled
+    assert all(torch.equal(a, b) for a, b in zip(sampled, before))  # ... the saved input of the pending backward is intact
+    assert torch.equal(lst[order[0]], bs[3])                         # next access: the new batch is there (list semantics)
+    assert torch.equal(sampled[0], bs[3])                            # (and the old view now shows it: same storage)
+    # two assignments in a row: the first is applied when the second is recorded
+    lst[0] = bs[1]
+    lst[1] = bs[0]
+    assert torch.equal(lst[0], bs[1]) and torch.equal(lst[1], bs[0])
+    # shape mismatch is refused at assignment time, not at flush time
+    try:
+        lst[0] = torch.zeros(1, 3, 4, 4)
+        assert False
+    except ValueError:
+        pass
+
+
+def test_torch_save_writes_the_references_own_format(tmp_path):
+    """utils.py:108-115 does torch.save({..., 'dis_list': dis_list_old}) with whatever object train.py holds: the file
+    must contain a plain Python list of CPU tensors (no ring, no class of this package) that config.py:323-331's
+    `checkpoint.get('dis_list', [])` / len() / indexing / append consume"""
+    import pickletools
+    bs = _batches(3)
+    lst = R.DeviceReplayList(1000, device='cpu')
+    for b in bs:
+        lst.append(b)
+    lst[1] = bs[0]                                                   # a pending assignment must be in the file
+    path = str(tmp_path / 'ckpt')
+    torch.save({'epoch': 2, 'dis_list': lst}, path)                  # as utils.py:108-115
+    import os
+    assert os.path.getsize(path) < 3 * bs[0].numel() * 4 + 16384    # three batches, not the 1000-entry ring
+    ck = torch.load(path, map_location='cpu', weights_only=False)    # config.py:311 (torch of the reference's era)
+    l = ck.get('dis_list', [])                                       # config.py:325
+    assert type(l) is list and len(l) == 3
+    assert torch.equal(l[0], bs[0]) and torch.equal(l[1], bs[0]) and torch.equal(l[2], bs[2])
+    l.append(bs[1])                                                  # train.py:71 on the loaded object
+    import zipfile
+    names = zipfile.ZipFile(path).namelist()
+    pk = zipfile.ZipFile(path).read([n for n in names if n.endswith('data.pkl')][0])
+    assert b'replay' not in pk and b'DeviceReplayList' not in pk    # readable without this package
+    with torch.serialization.safe_globals([list]):
+        ck2 = torch.load(path, map_location='cpu', weights_only=True)
+    assert type(ck2['dis_list']) is list and len(ck2['dis_list']) == 3
+    again = R.gen_dis_list(ck, 5, 'cpu', progressive_gan_suffix=0)
+    assert len(again) == 4
