@@ -307,27 +307,52 @@ def prepare_weights(items, training, need_dgrad=True):
     return out, (big, sm, tab_dev)
 
 
-_PIN_RING = {'buf': None, 'off': 0, 'half': 0, 'events': [None, None]}
+_PIN_RING = {'buf': None, 'off': 0, 'half': 0, 'events': [[], []], 'streams': {}}
 _PIN_CAPTURE = {'buf': None, 'off': 0}   # bump allocator for tables referenced by captured graphs
 _PIN_KEEP = []                           # ... whose pinned storage must outlive every replay
 _PIN_RING_BYTES = 4 << 20
+_PIN_CAPTURE_CHUNK = 1 << 20
+
+
+def reserve_capture_tables(nbytes):
+    """Make sure the pinned staging area for descriptor tables of CAPTURED launches has `nbytes` free -- called by
+    graph.GraphedStep BEFORE capture_begin with what its warm-up runs consumed: a pinned host allocation inside a
+    stream capture invalidates the capture (hipHostMalloc is not capturable), so the bump allocator must never have to
+    grow while one is running."""
+    cap = _PIN_CAPTURE
+    if cap['buf'] is None or cap['off'] + nbytes > cap['buf'].numel():
+        assert not torch.cuda.is_current_stream_capturing()
+        cap['buf'] = torch.empty(max(nbytes, _PIN_CAPTURE_CHUNK), dtype=torch.uint8, pin_memory=True)
+        cap['off'] = 0
+        _PIN_KEEP.append(cap['buf'])
+
+
+_TABLE_BYTES = [0]                       # bytes of tables staged so far (GraphedStep sizes its reservation from the delta)
+
+
+def table_bytes_staged():
+    return _TABLE_BYTES[0]
 
 
 def _table_to_device(table, dev):
     """Descriptor table -> device without a host synchronisation: staged in pinned memory and copied
-    asynchronously on the current stream.  Eager mode uses a 4 MB pinned ring in two halves: the last copy issued
-    from a half is followed by an event, and the host waits for that event before it writes into the half again
-    (normally long complete: a half holds thousands of tables), so a slot is never rewritten while its copy may
-    still be pending however far the GPU lags behind the host.  Under HIP-graph capture every table gets its own
-    pinned buffer that is kept alive forever, because the captured copy node re-reads it on each replay."""
+    asynchronously on the current stream.  Eager mode uses a 4 MB pinned ring in two halves: when a half is full an
+    event is recorded on EVERY stream that issued copies out of it (tables are also uploaded from warm-up side streams
+    and from the capture stream), and the host waits for those events before it writes into the half again (normally
+    long complete: a half holds thousands of tables), so a slot is never rewritten while its copy may still be pending
+    however far the GPU lags behind the host.  Under HIP-graph capture every table gets its own slice of a pinned
+    bump buffer that is kept alive forever, because the captured copy node re-reads it on each replay; GraphedStep
+    reserves that buffer before the capture begins (reserve_capture_tables)."""
     raw = bytes(table)
     n = (len(raw) + 255) & ~255
+    _TABLE_BYTES[0] += n
     if torch.cuda.is_current_stream_capturing():
         cap = _PIN_CAPTURE
         if cap['buf'] is None or cap['off'] + n > cap['buf'].numel():
-            cap['buf'] = torch.empty(max(n, 1 << 20), dtype=torch.uint8, pin_memory=True)
-            cap['off'] = 0
-            _PIN_KEEP.append(cap['buf'])
+            # not reserved (a caller capturing without GraphedStep): the allocation below invalidates the capture on
+            # ROCm 7.2 -- say why instead of failing later with a generic capture error
+            raise RuntimeError('descriptor-table staging exhausted inside a stream capture: call '
+                               'engine.reserve_capture_tables(nbytes) before capture_begin (GraphedStep does)')
         host = cap['buf'][cap['off']:cap['off'] + n]
         cap['off'] += n
         host[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
@@ -335,23 +360,27 @@ def _table_to_device(table, dev):
     ring = _PIN_RING
     if ring['buf'] is None:
         ring['buf'] = torch.empty(_PIN_RING_BYTES, dtype=torch.uint8, pin_memory=True)
-        _PIN_CAPTURE['buf'] = torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True)   # allocated OUTSIDE capture
-        _PIN_KEEP.append(_PIN_CAPTURE['buf'])
+        reserve_capture_tables(_PIN_CAPTURE_CHUNK)                          # allocated OUTSIDE capture
     half_bytes = _PIN_RING_BYTES // 2
     assert n <= half_bytes, 'descriptor table larger than half the pinned ring'
     if ring['off'] + n > (ring['half'] + 1) * half_bytes:          # this half is full: fence it, move to the other
-        ev = torch.cuda.Event()
-        ev.record()                                                 # after every copy issued from the full half
-        ring['events'][ring['half']] = ev
+        evs = []
+        for st in ring['streams'].values():                         # every stream that copied out of the full half
+            ev = torch.cuda.Event()
+            ev.record(st)
+            evs.append(ev)
+        ring['events'][ring['half']] = evs
+        ring['streams'] = {}
         ring['half'] ^= 1
         ring['off'] = ring['half'] * half_bytes
-        pending = ring['events'][ring['half']]
-        if pending is not None:
-            pending.synchronize()                                   # copies out of the half we are about to rewrite
-            ring['events'][ring['half']] = None
+        for ev in ring['events'][ring['half']]:
+            ev.synchronize()                                        # copies out of the half we are about to rewrite
+        ring['events'][ring['half']] = []
     host = ring['buf'][ring['off']:ring['off'] + n]
     ring['off'] += n
     host[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+    cur = torch.cuda.current_stream()
+    ring['streams'][cur.cuda_stream] = cur
     return host.to(dev, non_blocking=True)
 
 
@@ -389,7 +418,10 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
             fin.ensure()
     sp = cp = None
     if stats:
-        # rows of the statistics partials: one per tile, or one per workgroup on the persistent trunk kernel
+        # rows of the statistics partials: one per tile, or one per workgroup on the persistent trunk kernel.  The row
+        # count depends on which kernel takes the descriptor, and that depends on the fusions requested (the upscale
+        # variant of the trunk kernel has no statistics epilogue): ask with the statistics pointers already non-null
+        f.stat_part = f.cnt_part = f.y
         rows = (lib.sisr_conv2d_bf16_parts if prep.kinds[0] else lib.sisr_conv2d_f32_parts)(C.byref(f))
         sp = torch.empty((rows, 2, gm.cout), dtype=torch.float32, device=dev)
         cp = torch.empty((rows,), dtype=torch.float32, device=dev)

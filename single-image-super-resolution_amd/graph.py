@@ -99,11 +99,18 @@ class GraphedStep:
         dev = self._dev = torch.cuda.current_device()
         if self._via_worker and dev not in _TRIGGER:
             _TRIGGER[dev] = (torch.zeros(1, device='cuda:%d' % dev, requires_grad=True), torch.ones(1, device='cuda:%d' % dev))
+        from . import engine as E
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
+        per_run = 0
         with torch.cuda.stream(side):
             for _ in range(warmup):
+                before = E.table_bytes_staged()
                 fn()
+                per_run = max(per_run, E.table_bytes_staged() - before)
+        # the captured run stages as many descriptor-table bytes as a warm-up run did: have them (twice over) in pinned
+        # memory BEFORE the capture begins -- a pinned allocation inside a capture invalidates it
+        E.reserve_capture_tables(2 * per_run + (64 << 10))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         gc.collect()                       # no tensor of the warm-up runs may be freed in the middle of the capture

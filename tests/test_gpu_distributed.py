@@ -1,6 +1,7 @@
 """GPU: two data-parallel ranks of the real modules on one GPU (gloo): see tests/dp_rehearsal.py."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -10,11 +11,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def test_two_ranks_end_a_step_with_identical_parameters():
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     env['OMP_NUM_THREADS'] = '4'
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                        '--master-addr', '127.0.0.1', '--master-port', '29731', os.path.join(ROOT, 'tests', 'dp_rehearsal.py')],
+                        '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'dp_rehearsal.py')],
                        capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     if r.returncode != 0:
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
