@@ -16,17 +16,29 @@ from oracle import init as oinit  # noqa: E402
 PKG = 'single-image-super-resolution_amd'
 lr = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 init = sys.argv[2] if len(sys.argv) > 2 else 'default'
-mg = importlib.import_module(PKG + '.model_generator')
+what = sys.argv[3] if len(sys.argv) > 3 else 'gen'            # gen | gen_smooth | dis
 torch.manual_seed(0)
-net = mg.Generator(16, 64, 256, [2], use_sn=True).cuda().train()
+if what == 'dis':
+    md = importlib.import_module(PKG + '.model_discriminator')
+    feats, strides = [64, 64, 128, 128, 256, 256, 512, 512], [1, 2, 1, 2, 1, 2, 1, 2]
+    net = md.Discriminator((3, lr, lr), feats, strides).cuda().train()
+    cfg = {'kind': 'discriminator', 'list_stride': strides}
+else:
+    mg = importlib.import_module(PKG + '.model_generator')
+    net = mg.Generator(16, 64, 256, [2], use_sn=True).cuda().train()
+    cfg = {'kind': 'generator', 'list_scales': [2], 'n_suffix': 0}
 if init == 'default':
     state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
 else:
-    state = oinit.synth_state({k: tuple(v.shape) for k, v in net.state_dict().items()}, 5)
-g = torch.Generator().manual_seed(21)
+    state = oinit.synth_state({k: tuple(v.shape) for k, v in net.state_dict().items()}, 5 if what != 'dis' else 6)
+if what == 'gen_smooth':
+    gs = torch.Generator().manual_seed(3)
+    for k in state:
+        if k.endswith('.weight') and state[k].numel() == 1:
+            state[k] = 0.96 + 0.03 * torch.rand(state[k].shape, generator=gs)
+g = torch.Generator().manual_seed(21 if what != 'dis' else 22)
 x = torch.rand(16, 3, lr, lr, generator=g) * 2 - 1
-r = torch.rand(16, 3, 2 * lr, 2 * lr, generator=g) * 2 - 1
-cfg = {'kind': 'generator', 'list_scales': [2], 'n_suffix': 0}
+r = torch.rand(16, 3, 2 * lr, 2 * lr, generator=g) * 2 - 1 if what != 'dis' else torch.rand(16, 1, generator=g) * 2 - 1
 net.load_state_dict(state)
 xx = x.cuda().requires_grad_(True)
 out = net(xx)
