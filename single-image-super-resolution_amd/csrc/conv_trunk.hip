@@ -56,12 +56,14 @@ __device__ unsigned long long sisr_ttrace_buf[TT_WG * TT_SLOTS];
     do {                                                                                                        \
         if (threadIdx.x == 256 && blockIdx.x < TT_WG && 64 + (k) < TT_SLOTS) sisr_ttrace_buf[blockIdx.x * TT_SLOTS + 64 + (k)] = wall_clock64(); \
     } while (0)
+#define TTC(k) do { if (threadIdx.x == 0 && blockIdx.x < TT_WG) sisr_ttrace_buf[blockIdx.x * TT_SLOTS + (k)] = clock64(); } while (0)
 extern "C" int sisr_ttrace_read(void* dst, int n_u64) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sisr_ttrace_buf), (size_t)n_u64 * 8, 0, hipMemcpyDeviceToHost);
 }
 #else
 #define TT(k)
 #define TTP(k)
+#define TTC(k)
 #endif
 
 struct TrunkArgs {
@@ -206,6 +208,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     bool easy_slope = true;
 
     TT(0);
+    TTC(60);
     // deferred BatchNorm finalisation: scale / shift of the prologue's BatchNorm from its statistics rows, in LDS (the halo
     // buffers are free yet: 48 KB of scratch, the constants behind the reduction scratch)
     float* kfin = red + 4 * 32 * 3;
@@ -441,6 +444,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
         }
     }
     TT(63);
+    TTC(61);
 }
 
 

@@ -41,12 +41,15 @@ typedef unsigned cf_u32x4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long sisr_cftrace_buf[512 * 128];
 #define CFT(k) do { if (threadIdx.x == 0 && blockIdx.x < 512 && (k) < 64) sisr_cftrace_buf[blockIdx.x * 128 + (k)] = wall_clock64(); } while (0)
 #define CFTP(k) do { if (threadIdx.x == 256 && blockIdx.x < 512 && (k) < 64) sisr_cftrace_buf[blockIdx.x * 128 + 64 + (k)] = wall_clock64(); } while (0)
+// shader-clock stamps (s_memtime) at kernel start / end: in-kernel clock = delta(s_memtime) / delta(wall) x 100 MHz
+#define CFTC(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) sisr_cftrace_buf[blockIdx.x * 128 + (k)] = clock64(); } while (0)
 extern "C" int sisr_cftrace_read(void* dst, int n_u64) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sisr_cftrace_buf), (size_t)n_u64 * 8, 0, hipMemcpyDeviceToHost);
 }
 #else
 #define CFT(k)
 #define CFTP(k)
+#define CFTC(k)
 #endif
 
 struct CTrunkF32Args {
@@ -97,6 +100,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
     };
 
     CFT(0);
+    CFTC(60);
     // deferred BatchNorm finalisation: scale / shift of the prologue's BatchNorm from its statistics rows, in LDS (the halo
     // weights region is free yet: 48 KB of scratch; the constants behind the reduction scratch)
     float* kfin = red + 4 * 32 * 3;
@@ -438,6 +442,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
         }
     }
     CFT(63);
+    CFTC(61);
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------

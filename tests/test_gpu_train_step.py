@@ -189,7 +189,11 @@ def test_overwriting_a_sampled_replay_entry_between_forward_and_backward():
         lst[k] = curr.to(dev) * float(k + 2)                      # train.py:68-69, on every slot D has just read
     err.backward()                                                # train.py:74
     got = {k: p.grad.detach().cpu() for k, p in net_d.named_parameters()}
-    assert grads_close(got, grads_ref, TOL) == []
+    # (2e-2, not 1e-3: five D forwards of 0.5-1 M LeakyReLU(0.01) activations each see the occasional mask flip of a
+    # pre-activation within rounding of zero, worth up to ~5e-3 on one tensor; a first conv fed with the overwritten batch
+    # would be off by O(1))
+    assert grads_close(got, grads_ref, 2e-2) == []
+    assert rel_err(got['conv.0.weight_orig'], grads_ref['conv.0.weight_orig']) < 5e-3
     assert torch.equal(lst[2].cpu(), curr * 4.0) and torch.equal(lst[0].cpu(), curr * 2.0)
 
 

@@ -17,6 +17,8 @@ t = buf.reshape(512, slots).astype(np.int64) * 10e-3
 t = t[t[:, 0] > 0]
 t0 = t[:, 0].min()
 print('%d workgroups; kernel span %.2f us; lifetime avg %.2f; start spread %.2f' % (len(t), t[:, 63].max() - t0, (t[:, 63] - t[:, 0]).mean(), (t[:, 0] - t0).max()))
+ck = (t[:, 61] - t[:, 60]) / 10e-3 / ((t[:, 63] - t[:, 0]) * 100.0)      # raw ticks / (us x 100 ticks per us)
+print('in-kernel shader clock (s_memtime / s_memrealtime): median %.3f GHz' % (float(np.median(ck)) / 10.0))
 print('prologue (weights to registers / first tile staged, barrier) +%.2f' % (t[:, 4] - t[:, 0]).mean())
 for it in range(8):
     b = 4 + 6 * it
