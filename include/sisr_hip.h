@@ -303,6 +303,13 @@ int sisr_bn_bwd_plan(SisrBnBwdDesc *d);
 int sisr_bn_bwd(const SisrBnBwdDesc *d, void *stream);
 /* second half only: `work` holds d->grid partial rows [2*C+1] written by a conv epilogue (SisrConvDesc.bnb_part) */
 int sisr_bn_bwd_finalize(const SisrBnBwdDesc *d, void *stream);
+/* the same launch also carries a slab reduction (sisr_slab_reduce_f32's arguments) in additional workgroups: the
+ * finishing step of a BatchNorm backward (a few latency-bound workgroups) and the slab sum of the weight gradient
+ * computed just before it (hundreds of bandwidth-bound ones) are independent and adjacent in the backward schedule of
+ * a residual block (model_generator.py:16-19 differentiated), so one launch replaces two -- 33 fewer per step.  Both
+ * results are bit-identical to the separate launches. */
+int sisr_bn_bwd_finalize_slab(const SisrBnBwdDesc *d, const float *slab, float *out, int32_t n_slabs, int64_t elems,
+                              void *stream);
 
 /* elementwise: y = f(x1) + (pa ? pa[c]*x2 + pd[c] : x2)   over NHWC [P][C];
  * f = lrelu(., slope1_p ? *slope1_p : slope1) -- the residual add of BasicBlock.forward (model_generator.py:19) and the

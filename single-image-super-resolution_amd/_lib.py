@@ -125,6 +125,7 @@ _SIGS = {
     'sisr_bn_bwd_plan': [C.POINTER(BnBwdDesc)],
     'sisr_bn_bwd': [C.POINTER(BnBwdDesc), _f],
     'sisr_bn_bwd_finalize': [C.POINTER(BnBwdDesc), _f],
+    'sisr_bn_bwd_finalize_slab': [C.POINTER(BnBwdDesc), _f, _f, _i32, _i64, _f],
     'sisr_eltwise_res_affine': [_f, _f, _f32, _f, _f, _f, _f, _i64, _i32, _i32, _f],
     'sisr_prelu_slope_grad': [_f, _f, _i64, _f, _f, _i32, _f],
     'sisr_add': [_f, _f, _f, _i64, _i32, _f],

@@ -66,6 +66,23 @@ extern "C" int sisr_ttrace_read(void* dst, int n_u64) {
 #define TTC(k)
 #endif
 
+// barrier-wait accounting, developer build only (-DSISR_BARRIER_ACCT; tools/barrier_acct.py): every tile-loop barrier of the
+// forward kernel is bracketed by two s_memtime reads whose difference is summed in SGPRs -- no stores, no LDS drain inside
+// the loop -- and lane 0 of wave 0 (consumer) / wave 4 (producer) stores {loop cycles, cycles spent waiting at barriers}
+#ifdef SISR_BARRIER_ACCT
+__device__ unsigned long long sisr_bacct_buf[512 * 4];
+extern "C" int sisr_bacct_read(void* dst, int n_u64) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sisr_bacct_buf), (size_t)n_u64 * 8, 0, hipMemcpyDeviceToHost);
+}
+#define BA_DECL unsigned long long ba_wait = 0, ba_t0 = clock64()
+#define BA_SYNC() do { const unsigned long long b0_ = clock64(); __syncthreads(); ba_wait += clock64() - b0_; } while (0)
+#define BA_STORE(slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) { sisr_bacct_buf[blockIdx.x * 4 + (slot)] = clock64() - ba_t0; sisr_bacct_buf[blockIdx.x * 4 + (slot) + 1] = ba_wait; } } while (0)
+#else
+#define BA_DECL
+#define BA_SYNC() __syncthreads()
+#define BA_STORE(slot)
+#endif
+
 struct TrunkArgs {
     const void *x1, *x2;                  // input operand(s), bf16 NHWC [N][H][W][64]
     void* x_out;                          // skip-sum prologue: the materialised operand
@@ -165,7 +182,13 @@ __device__ __forceinline__ u32x4 trunk_apply8(u32x4 a, u32x4 b, const f32x8& ka,
 // and one memory / VALU-heavy wave.  One workgroup barrier per tile.
 #define TK_THREADS 512
 #ifndef TK_PF
-#define TK_PF 3                           // A-fragment prefetch distance of the consumers' MFMA loop, in steps of 2 MFMAs
+#define TK_PF 3                           // A-fragment prefetch distance of the data-gradient consumers' MFMA loop, in steps of 2 MFMAs
+#endif
+#ifndef TK_DEFER
+#define TK_DEFER 0                        // 1: also defer sub-tile 1's epilogue under the next tile's first phase (A/B variant)
+#endif
+#ifndef TK_PFA
+#define TK_PFA 4                          // ... of the forward consumers' phases, in MFMAs (5 and more spill: 256 VGPRs are in use)
 #endif
 template <int PRO>
 __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const TrunkArgs a) {
@@ -302,6 +325,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
         if (T < a.total) commit(lds, stA);
         TTP(2);
         __syncthreads();
+        BA_DECL;
         // unrolled by two: each staging set has a fixed name in each half (stB holds tile T + grid in the first)
         int cur = 0;
         [[maybe_unused]] int it = 0;
@@ -311,7 +335,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
             TTP(5 + 6 * it);
             if (T + t_step < a.total) commit(lds + (cur ^ 1) * TK_HALO_BYTES, stB);
             TTP(8 + 6 * it);
-            __syncthreads();
+            BA_SYNC();
             TTP(9 + 6 * it);
             T += t_step; cur ^= 1; ++it;
             if (T >= a.total) break;
@@ -320,96 +344,152 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
             TTP(5 + 6 * it);
             if (T + t_step < a.total) commit(lds + (cur ^ 1) * TK_HALO_BYTES, stA);
             TTP(8 + 6 * it);
-            __syncthreads();
+            BA_SYNC();
             TTP(9 + 6 * it);
             T += t_step; cur ^= 1; ++it;
         }
+        // (the always-executed prefetch loads past the last tile are still in flight: wait for them HERE, so that the
+        // role join below carries no pending load -- with one, the compiler's wait-count bookkeeping makes the consumers
+        // drain their output stores, ~2 us, before the statistics tail)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+        if (wave == 4) BA_STORE(2);
     } else {
         init_consumer();
         TT(2);
         __syncthreads();
-        int cur = 0, it = 0;
-        for (int T = t_first; T < a.total; T += t_step, cur ^= 1, ++it) {
-            TT(4 + 6 * it);
-            {
-            // ---- consumer: MFMA phase (2 sub-tiles x 9 taps x 4 K-steps; every A address is base + immediate) ... -------
-            f32x16 acc[2];
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the weights (long here: the barrier took microseconds)
+        // ---- consumers.  A tile is two sub-tiles of 32 pixels (tile rows 4g + 2ms, 4g + 2ms + 1) x this wave's 32 couts,
+        // 36 MFMAs each (9 taps x 4 K slices; every A address is base + immediate, B is in registers).  The epilogue of a
+        // sub-tile -- statistics, bf16 conversion, transpose through LDS, 16-byte stores -- is software-pipelined UNDER the
+        // MFMAs of the next sub-tile: sub-tile 0's under sub-tile 1's of the same tile, sub-tile 1's under sub-tile 0's of
+        // the NEXT tile (its accumulators live across the barrier).  Written out in six slices that are placed between
+        // fixed MFMAs (sched_barrier pins the source order), so the matrix pipe never waits for an epilogue: before, every
+        // tile ended with 0.62 us of epilogue while the pipe was idle (profiles/r02_trace_trunk_fwd.txt).
+        const __amdgpu_buffer_rsrc_t ry = bf_rsrc(a.y, a.shuffle ? 4u * xbytes : xbytes);
+        auto consumer_loop = [&](auto STATS_) {
+            constexpr bool STATS = decltype(STATS_)::value;
+            f32x16 acc0, acc1;
+            // slice sl (0 .. 5) of the epilogue of sub-tile ms whose accumulators are `acc`, tile (n, ty, tx):
+            //   0 .. 3  register group q = sl: statistics of its 4 values, bf16, 8-byte LDS store into the wave's
+            //           [32 couts][64 pixels] image (pixels 32 ms + 8 q + 4 kk .. + 3 of cout l31)
+            //   4, 5    16-pixel block pb = 2 ms + (sl - 4) = tile row 4 g + pb: transposing reads, one 16-byte store
+            auto epi = [&](int sl, const f32x16& acc, int ms, bool first, int n, int ty, int tx) {
+                if (sl < 4) {
+                    const int q = sl;
+                    if (STATS) {
+                        if (first && q == 0) {                      // shift = mean of the first sub-tile's values of this lane
+                            float sm = 0.f;
 #pragma unroll
-            for (int ms = 0; ms < 2; ++ms)
+                            for (int i = 0; i < 16; ++i) sm += acc[i];
+                            st_shift = sm * (1.f / 16.f);
+                        }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[ms][i] = bv;          // the bias: every register of a lane is its channel
-            const unsigned char* ib = lds + cur * (TK_HALO_BYTES);
-            // software pipeline: the A fragments of step s + TK_PF are requested before the two MFMAs of step s
-            // (step = tap t, K slice j; left to itself the compiler keeps one step of reads in flight, ~64 cycles of cover)
-            bf16x8 af[36][2];
-            auto fetch = [&](int st) {
-                const int t = st >> 2, j = st & 3;
-                const int toff = (t / 3) * TK_RP + (t % 3) * TK_PSB;
-#pragma unroll
-                for (int ms = 0; ms < 2; ++ms) af[st][ms] = *reinterpret_cast<const bf16x8*>(ib + a_base[ms] + toff + j * 32);
-            };
-#pragma unroll
-            for (int st = 0; st < TK_PF; ++st) fetch(st);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TK_PF, 0);
-#pragma unroll
-            for (int st = 0; st < 36; ++st) {
-                if (st + TK_PF < 36) fetch(st + TK_PF);
-#pragma unroll
-                for (int ms = 0; ms < 2; ++ms)
-                    acc[ms] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st][ms], bw[st >> 2][st & 3], acc[ms], 0, 0, 0);
-                if (st + TK_PF < 36) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            }
-            TT(6 + 6 * it);
-            // ---- ... and epilogue: bias, statistics, bf16, transposed store -------------------------------------------------
-            const __amdgpu_buffer_rsrc_t ry = bf_rsrc(a.y, a.shuffle ? 4u * xbytes : xbytes);
-            int n, ty, tx;
-            tile_coords(T, n, ty, tx);
-            if (a.stat_part != nullptr) {
-                if (st_n == 0) {                                    // shift = mean of the first tile's values of this lane
-                    float s = 0.f;
-#pragma unroll
-                    for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) s += acc[ms][i];
-                    st_shift = s * (1.f / 32.f);
-                }
-#pragma unroll
-                for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float dv = acc[ms][i] - st_shift;
-                        st_s1 += dv;
-                        st_s2 += dv * dv;
+                        for (int j = 0; j < 4; ++j) {
+                            const float dv = acc[4 * q + j] - st_shift;
+                            st_s1 += dv;
+                            st_s2 += dv * dv;
+                        }
+                        if (q == 3) st_n += 16;
                     }
-                st_n += 32;
-            }
-#pragma unroll
-            for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
                     bf16x4 hv;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { const float v = acc[ms][4 * q + j]; hv[j] = (__bf16)v; }
-                    // register group q of sub-tile ms = pixels 32ms + 8q + 4kk .. +3 of this wave's 64
+                    for (int j = 0; j < 4; ++j) hv[j] = (__bf16)acc[4 * q + j];
                     *reinterpret_cast<bf16x4*>(my_out + l31 * TK_YS + 32 * ms + 8 * q + 4 * kk) = hv;
+                } else {
+                    const int pb = 2 * ms + (sl - 4);               // group = channel octet
+                    const __bf16* src = my_out + (8 * grp + tq) * TK_YS + 16 * pb + 4 * tp;
+                    const s16x4 lo = lds_tr16(src), hi = lds_tr16(src + 4 * TK_YS);
+                    const s16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const int oy = ty * TK_TH + 4 * g + pb, ox = tx * TK_TW + (lane & 15);
+                    // PixelShuffle(2) on store: phase cg = (i, j) of this workgroup's couts lands on pixel (2 oy + i, 2 ox + j)
+                    const unsigned vo = a.shuffle ? (unsigned)(((n * 2 * a.H + 2 * oy + (cg >> 1)) * 2 * a.W + 2 * ox + (cg & 1)) * 128 + (32 * h + 8 * grp) * 2)
+                                                  : (unsigned)(((n * a.H + oy) * a.W + ox) * 128 + (32 * h + 8 * grp) * 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v8), ry, vo, 0, 0);
                 }
+            };
+            // after which MFMA of a 36-MFMA phase each slice goes (the head of a phase stays MFMA-only: the matrix pipe
+            // starts at once behind the barrier; the stores go last so the data gradient's / next layer's loads see them early
+            // enough without crowding the head)
+            auto slice_at = [](int c) { return c == 5 ? 0 : c == 10 ? 1 : c == 15 ? 2 : c == 20 ? 3 : c == 27 ? 4 : c == 33 ? 5 : -1; };
+            // one phase: 36 MFMAs into `acc` over sub-tile `ms` of halo image `ib`; `under(c)` runs after MFMA c
+            auto phase = [&](f32x16& acc, const unsigned char* ib, int ms, auto&& under) {
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) {                        // 16-pixel block pb = tile row 4g + pb; group = octet
-                const __bf16* src = my_out + (8 * grp + tq) * TK_YS + 16 * pb + 4 * tp;
-                const s16x4 lo = lds_tr16(src), hi = lds_tr16(src + 4 * TK_YS);
-                const s16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                const int oy = ty * TK_TH + 4 * g + pb, ox = tx * TK_TW + (lane & 15);
-                // PixelShuffle(2) on store: phase cg = (i, j) of this workgroup's couts lands on pixel (2 oy + i, 2 ox + j)
-                const unsigned vo = a.shuffle ? (unsigned)(((n * 2 * a.H + 2 * oy + (cg >> 1)) * 2 * a.W + 2 * ox + (cg & 1)) * 128 + (32 * h + 8 * grp) * 2)
-                                              : (unsigned)(((n * a.H + oy) * a.W + ox) * 128 + (32 * h + 8 * grp) * 2);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v8), ry, vo, 0, 0);
+                for (int i = 0; i < 16; ++i) acc[i] = bv;           // the bias: every register of a lane is its channel
+                bf16x8 af[36];
+                const unsigned char* pa = ib + a_base[ms];
+                auto fetch = [&](int st) {
+                    const int t = st >> 2, j = st & 3;
+                    af[st] = *reinterpret_cast<const bf16x8*>(pa + (t / 3) * TK_RP + (t % 3) * TK_PSB + j * 32);
+                };
+#pragma unroll
+                for (int st = 0; st < TK_PFA; ++st) fetch(st);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int st = 0; st < 36; ++st) {
+                    if (st + TK_PFA < 36) fetch(st + TK_PFA);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st], bw[st >> 2][st & 3], acc, 0, 0, 0);
+                    under(st);
+                    __builtin_amdgcn_sched_barrier(0);              // the source order IS the software pipeline
+                }
+            };
+            int cur = 0, it = 0;
+            int n, ty, tx;
+            BA_DECL;
+#if TK_DEFER
+            // sub-tile 1's epilogue deferred under the NEXT tile's first phase (its accumulators live across the barrier)
+            int T = t_first, pn = 0, pty = 0, ptx = 0;
+            if (T < a.total) {
+                // first tile (peeled): nothing to finish under its first phase
+                TT(4);
+                tile_coords(T, n, ty, tx);
+                phase(acc0, lds, 0, [&](int) {});
+                TT(6);
+                phase(acc1, lds, 1, [&](int c) { const int sl = slice_at(c); if (sl >= 0) epi(sl, acc0, 0, true, n, ty, tx); });
+                TT(8);
+                BA_SYNC();            // the next tile's image is complete; the consumers have finished reading this one
+                TT(9);
+                pn = n; pty = ty; ptx = tx;
+                T += t_step; cur ^= 1; ++it;
             }
+            for (; T < a.total; T += t_step, cur ^= 1, ++it) {
+                TT(4 + 6 * it);
+                tile_coords(T, n, ty, tx);
+                const unsigned char* ib = lds + cur * (TK_HALO_BYTES);
+                phase(acc0, ib, 0, [&](int c) { const int sl = slice_at(c); if (sl >= 0) epi(sl, acc1, 1, false, pn, pty, ptx); });
+                TT(6 + 6 * it);
+                phase(acc1, ib, 1, [&](int c) { const int sl = slice_at(c); if (sl >= 0) epi(sl, acc0, 0, false, n, ty, tx); });
+                TT(8 + 6 * it);
+                BA_SYNC();
+                TT(9 + 6 * it);
+                pn = n; pty = ty; ptx = tx;
             }
-            TT(8 + 6 * it);
-            __syncthreads();      // the next tile's image is complete; the consumers have finished reading this one
-            TT(9 + 6 * it);
-        }
+            if (it > 0) {                                           // the last tile's second sub-tile
+#pragma unroll
+                for (int sl = 0; sl < 6; ++sl) epi(sl, acc1, 1, false, pn, pty, ptx);
+            }
+#else
+            // sub-tile 0's epilogue under sub-tile 1's MFMAs; sub-tile 1's own epilogue follows its phase (no accumulator
+            // is carried around the loop: that costs the allocator 16 registers, which buy a deeper A prefetch here)
+            for (int T = t_first; T < a.total; T += t_step, cur ^= 1, ++it) {
+                TT(4 + 6 * it);
+                tile_coords(T, n, ty, tx);
+                const unsigned char* ib = lds + cur * (TK_HALO_BYTES);
+                phase(acc0, ib, 0, [&](int) {});
+                TT(6 + 6 * it);
+                const bool first = it == 0;
+                phase(acc1, ib, 1, [&](int c) { const int sl = slice_at(c); if (sl >= 0) epi(sl, acc0, 0, first, n, ty, tx); });
+#pragma unroll
+                for (int sl = 0; sl < 6; ++sl) epi(sl, acc1, 1, false, n, ty, tx);
+                TT(8 + 6 * it);
+                BA_SYNC();
+                TT(9 + 6 * it);
+            }
+#endif
+            TT(1);
+            if (wave == 0) BA_STORE(0);
+        };
+        if (a.stat_part != nullptr) consumer_loop(std::true_type{});
+        else consumer_loop(std::false_type{});
     }
     TT(3);
 

@@ -42,7 +42,11 @@ __device__ unsigned long long sisr_cftrace_buf[512 * 128];
 #define CFT(k) do { if (threadIdx.x == 0 && blockIdx.x < 512 && (k) < 64) sisr_cftrace_buf[blockIdx.x * 128 + (k)] = wall_clock64(); } while (0)
 #define CFTP(k) do { if (threadIdx.x == 256 && blockIdx.x < 512 && (k) < 64) sisr_cftrace_buf[blockIdx.x * 128 + 64 + (k)] = wall_clock64(); } while (0)
 // shader-clock stamps (s_memtime) at kernel start / end: in-kernel clock = delta(s_memtime) / delta(wall) x 100 MHz
-#define CFTC(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) sisr_cftrace_buf[blockIdx.x * 128 + (k)] = clock64(); } while (0)
+__device__ unsigned long long sisr_cfclk_buf[512 * 2];
+#define CFTC(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) sisr_cfclk_buf[blockIdx.x * 2 + ((k) - 60)] = clock64(); } while (0)
+extern "C" int sisr_cfclk_read(void* dst, int n_u64) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sisr_cfclk_buf), (size_t)n_u64 * 8, 0, hipMemcpyDeviceToHost);
+}
 extern "C" int sisr_cftrace_read(void* dst, int n_u64) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sisr_cftrace_buf), (size_t)n_u64 * 8, 0, hipMemcpyDeviceToHost);
 }

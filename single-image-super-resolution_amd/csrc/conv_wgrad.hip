@@ -170,29 +170,11 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_f32_kernel(const Sis
 // out[i] = sum_k slab[k][i]: 16 float4 columns x 16 slab-splits per workgroup, combined through LDS in a fixed order
 // (deterministic).  The reduction is latency-bound, not bandwidth-bound (a few hundred slabs of ~150 KB, L2 / MALL
 // resident): many short independent load chains beat few long ones.
-#define SR_COLS 16
-#define SR_SPLITS (SISR_BLOCK / SR_COLS)
 __global__ void __launch_bounds__(SISR_BLOCK) slab_reduce_kernel(const float* __restrict__ slab,
                                                                 float* __restrict__ out, int n_slabs,
                                                                 int64_t elems) {
     __shared__ f32x4 sh[SR_SPLITS][SR_COLS];
-    const int col = threadIdx.x & (SR_COLS - 1), split = threadIdx.x / SR_COLS;
-    const int64_t i4 = (int64_t)blockIdx.x * SR_COLS + col;
-    const int64_t n4 = elems >> 2;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (i4 < n4) {
-#pragma unroll 8
-        for (int k = split; k < n_slabs; k += SR_SPLITS)
-            s += *reinterpret_cast<const f32x4*>(slab + (int64_t)k * elems + i4 * 4);
-    }
-    sh[split][col] = s;
-    __syncthreads();
-    if (split == 0 && i4 < n4) {
-        f32x4 t = sh[0][col];
-#pragma unroll
-        for (int j = 1; j < SR_SPLITS; ++j) t += sh[j][col];
-        *reinterpret_cast<f32x4*>(out + i4 * 4) = t;
-    }
+    slab_reduce_block(slab, out, n_slabs, elems, blockIdx.x, sh);
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_reduce_kernel(const SisrBnB
 #ifndef BWF_CH
 #define BWF_CH 4
 #endif
-__global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_finalize_kernel(const SisrBnBwdDesc d) {
+__device__ __forceinline__ void bn_bwd_finalize_block(const SisrBnBwdDesc& d, int block) {
     // workgroup = 4 channels x 64 row-splits over the per-workgroup partial rows of the reduce kernel: a thread
     // sums ~grid/64 rows with independent loads (double accumulation), lanes of one channel combine by
     // shuffles, the 4 waves through LDS -- fixed order, deterministic
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_finalize_kernel(const SisrB
     const int stride = 2 * d.C + 1;
     const double inv_n = 1.0 / (double)d.P;
     const int cl = threadIdx.x & (BWF_CH - 1), split = threadIdx.x / BWF_CH, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * BWF_CH + cl;
+    const int c = block * BWF_CH + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < d.C) {
 #pragma unroll 4
@@ -163,11 +163,26 @@ __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_finalize_kernel(const SisrB
         d.dgamma[c] = (float)s2;
         d.dbeta[c] = (float)s1;
     }
-    if (d.dslope != nullptr && blockIdx.x == 0) {
+    if (d.dslope != nullptr && block == 0) {
         float part = 0.f;
         for (int b = threadIdx.x; b < d.grid; b += SISR_BLOCK) part += d.work[(int64_t)b * stride + 2 * d.C];
         const float tot = block_sum(part, scratch);
         if (threadIdx.x == 0) d.dslope[0] = tot;
+    }
+}
+
+__global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_finalize_kernel(const SisrBnBwdDesc d) { bn_bwd_finalize_block(d, blockIdx.x); }
+
+// one launch, two independent jobs: workgroups [0, fin_blocks) finish the BatchNorm backward, the rest sum the slabs of the
+// weight gradient computed just before (sisr_bn_bwd_finalize_slab)
+__global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_finalize_slab_kernel(const SisrBnBwdDesc d, int fin_blocks,
+                                                                         const float* __restrict__ slab, float* __restrict__ out,
+                                                                         int n_slabs, int64_t elems) {
+    if ((int)blockIdx.x < fin_blocks) {
+        bn_bwd_finalize_block(d, blockIdx.x);
+    } else {
+        __shared__ f32x4 sh[SR_SPLITS][SR_COLS];
+        slab_reduce_block(slab, out, n_slabs, elems, (int)blockIdx.x - fin_blocks, sh);
     }
 }
 
@@ -325,6 +340,20 @@ extern "C" int sisr_bn_bwd_finalize(const SisrBnBwdDesc* d, void* stream) {
         d->grid <= 0 || d->C <= 0 || d->P <= 0)
         return SISR_E_BADARG;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + BWF_CH - 1) / BWF_CH), dim3(SISR_BLOCK), 0, S_(stream), *d);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_bn_bwd_finalize_slab(const SisrBnBwdDesc* d, const float* slab, float* out, int32_t n_slabs, int64_t elems,
+                                         void* stream) {
+    if (!d || !d->invstd || !d->mean || !d->gamma || !d->work || !d->qa || !d->qb || !d->qd || !d->dgamma || !d->dbeta ||
+        d->grid <= 0 || d->C <= 0 || d->P <= 0)
+        return SISR_E_BADARG;
+    if (!slab || !out || n_slabs <= 0 || elems <= 0 || (elems & 3)) return SISR_E_BADARG;
+    const int fin_blocks = (d->C + BWF_CH - 1) / BWF_CH;
+    const int slab_blocks = (int)((elems / 4 + SR_COLS - 1) / SR_COLS);
+    hipLaunchKernelGGL(bn_bwd_finalize_slab_kernel, dim3(fin_blocks + slab_blocks), dim3(SISR_BLOCK), 0, S_(stream), *d, fin_blocks,
+                       slab, out, n_slabs, elems);
     SISR_CHECK_LAUNCH();
     return 0;
 }

@@ -38,6 +38,32 @@ static inline int sisr_raise_lds_cap(SisrLdsCap& cap, const void* fn, int bytes,
     return 0;
 }
 
+// fixed-order sum of per-workgroup partial slabs (slab_reduce_kernel, conv_wgrad.hip; also carried by the combined
+// BatchNorm-backward finishing launch of norm.hip): 16 columns of 16 bytes x 16 slab splits per 256-thread workgroup --
+// many short independent load chains beat few long ones
+#define SR_COLS 16
+#define SR_SPLITS (SISR_BLOCK / SR_COLS)
+__device__ __forceinline__ void slab_reduce_block(const float* __restrict__ slab, float* __restrict__ out, int n_slabs,
+                                                  int64_t elems, int block, f32x4 (*sh)[SR_COLS]) {
+    const int col = threadIdx.x & (SR_COLS - 1), split = threadIdx.x / SR_COLS;
+    const int64_t i4 = (int64_t)block * SR_COLS + col;
+    const int64_t n4 = elems >> 2;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i4 < n4) {
+#pragma unroll 8
+        for (int k = split; k < n_slabs; k += SR_SPLITS)
+            s += *reinterpret_cast<const f32x4*>(slab + (int64_t)k * elems + i4 * 4);
+    }
+    sh[split][col] = s;
+    __syncthreads();
+    if (split == 0 && i4 < n4) {
+        f32x4 t = sh[0][col];
+#pragma unroll
+        for (int j = 1; j < SR_SPLITS; ++j) t += sh[j][col];
+        *reinterpret_cast<f32x4*>(out + i4 * 4) = t;
+    }
+}
+
 // leaky-relu family: PReLU (shared slope), LeakyReLU(0.01), ReLU (slope 0), identity (slope 1)
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
 

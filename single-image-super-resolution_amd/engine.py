@@ -525,8 +525,30 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
     return out if bnb is None else (out, part)
 
 
-def conv_wgrad(prep, x_op, dy_op):
-    """Weight + bias gradient in packed layout: returns the reduced [slab_elems + CoutPad] buffer."""
+class PendingSlabs:
+    """Slab reductions that have not been launched yet.  conv_wgrad(..., defer=pending) leaves the fixed-order sum of
+    its per-workgroup slabs here instead of launching sisr_slab_reduce_f32; the next bn_backward(..., part=rows,
+    slabs=pending) carries one of them in ITS launch (sisr_bn_bwd_finalize_slab: the two jobs are independent and
+    adjacent in a residual block's backward schedule -- one launch instead of two), and flush() launches whatever is
+    left the ordinary way.  The reduced buffers are valid in stream order after either."""
+
+    def __init__(self):
+        self.jobs = []                      # (slab tensor, reduced tensor, n_slabs, stride)
+
+    def pop(self):
+        return self.jobs.pop(0) if self.jobs else None
+
+    def flush(self):
+        lib = L.lib()
+        while self.jobs:
+            slab, red, n_slabs, stride = self.jobs.pop(0)
+            L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), red.data_ptr(), n_slabs, stride, _stream()),
+                    'sisr_slab_reduce_f32')
+
+
+def conv_wgrad(prep, x_op, dy_op, defer=None):
+    """Weight + bias gradient in packed layout: returns the reduced [slab_elems + CoutPad] buffer.
+    defer (PendingSlabs or None): leave the slab reduction to a later launch (see PendingSlabs)."""
     lib = L.lib()
     g = _copy_struct(prep.plans[2])
     cout = prep.ref.geom.cout
@@ -559,6 +581,9 @@ def conv_wgrad(prep, x_op, dy_op):
     else:
         L.check(lib.sisr_conv2d_wgrad_f32(C.byref(g), _stream()), 'sisr_conv2d_wgrad_f32')
     red = torch.empty((stride,), dtype=torch.float32, device=dev)
+    if defer is not None and os.environ.get('SISR_FUSE_SLABRED', '1') != '0':
+        defer.jobs.append((slab, red, n_slabs, stride))
+        return red
     L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), red.data_ptr(), n_slabs, stride, _stream()),
             'sisr_slab_reduce_f32')
     return red
@@ -659,10 +684,11 @@ def bn_eval_consts(bn, eps=1e-5):
     return k
 
 
-def bn_backward(dy, x, consts, gamma, slope=None, part=None):
+def bn_backward(dy, x, consts, gamma, slope=None, part=None, slabs=None):
     """Reductions of BatchNorm backward (+ the leaky activation after it when slope is given).
     Returns (q [3,C] = qa,qb,qd ; dgamma ; dbeta ; dslope or None).  part: per-tile partial rows already written
-    by the conv that produced dy (conv_dgrad(..., bnb=...)); only the finishing kernel runs then."""
+    by the conv that produced dy (conv_dgrad(..., bnb=...)); only the finishing kernel runs then -- and, given `slabs`
+    (PendingSlabs), that launch also carries one deferred slab reduction."""
     lib = L.lib()
     cch = x.shape[-1]
     d = L.BnBwdDesc()
@@ -692,7 +718,13 @@ def bn_backward(dy, x, consts, gamma, slope=None, part=None):
     if part is None:
         L.check(lib.sisr_bn_bwd(C.byref(d), _stream()), 'sisr_bn_bwd')
     else:
-        L.check(lib.sisr_bn_bwd_finalize(C.byref(d), _stream()), 'sisr_bn_bwd_finalize')
+        job = slabs.pop() if slabs is not None else None
+        if job is not None:                     # this launch also sums the slabs of the weight gradient computed before it
+            slab, red, n_slabs, stride = job
+            L.check(lib.sisr_bn_bwd_finalize_slab(C.byref(d), slab.data_ptr(), red.data_ptr(), n_slabs, stride, _stream()),
+                    'sisr_bn_bwd_finalize_slab')
+        else:
+            L.check(lib.sisr_bn_bwd_finalize(C.byref(d), _stream()), 'sisr_bn_bwd_finalize')
     return q, dgamma, dbeta, dslope
 
 

@@ -169,12 +169,14 @@ def run_backward(sv, grad_out, need_dx, sink=None, params=()):
     grad_out = grad_out.contiguous()
     grads = {}
     wg = E.WeightGradBatch()
+    pending = E.PendingSlabs()            # slab sums of the weight gradients, carried by the next BatchNorm-backward finish
     by_id = {id(p): p for p in params}
     announced = set()
     all_refs = [r for r in topo.conv_refs() if r is not None]
 
     def flush(tag):
         """un-pack the weight gradients collected so far (one launch) and announce every new gradient to the sink"""
+        pending.flush()
         for ref_id, (gw, gb) in wg.run().items():
             ref = next(r for r in all_refs if id(r) == ref_id)
             if gw is not None:
@@ -194,7 +196,7 @@ def run_backward(sv, grad_out, need_dx, sink=None, params=()):
         p = P[id(ref)]
         want_w, want_b = ref.weight.requires_grad, ref.bias is not None and ref.bias.requires_grad
         if want_w or want_b:
-            wg.add(p, E.conv_wgrad(p, x_op, dy_op), want_w, want_b)
+            wg.add(p, E.conv_wgrad(p, x_op, dy_op, defer=pending), want_w, want_b)
         if not need_dgrad:
             return None
         if bnb is None:
@@ -229,7 +231,7 @@ def run_backward(sv, grad_out, need_dx, sink=None, params=()):
     # ---- trunk end: conv + BN (+ long skip) ----------------------------------------------------------
     g_t = g                                               # grad wrt BN_e output (and wrt t0 via the skip)
     bn = topo.trunk_bn
-    q, dgam, dbet, _ = E.bn_backward(g_t, sv.ce, sv.ke, bn.weight, part=part)
+    q, dgam, dbet, _ = E.bn_backward(g_t, sv.ce, sv.ke, bn.weight, part=part, slabs=pending)
     grads[id(bn.weight)], grads[id(bn.bias)] = dgam, dbet
     dy = Operand(g_t, tuple(sv.ce.shape), pro=L.PRO_BNBWD, x2=sv.ce, pa=q[0], pb=q[1], pd=q[2])
     xl_op = Operand.act(sv.xl_raw, sv.xl_slope) if sv.xl_slope is not None else Operand.plain(sv.xl_raw)
@@ -244,12 +246,12 @@ def run_backward(sv, grad_out, need_dx, sink=None, params=()):
         flush('tail')
     # ---- residual blocks, last to first ----------------------------------------------------------------
     for bi, (b, rec) in enumerate(rblocks):
-        q2, dgam, dbet, _ = E.bn_backward(g, rec.c2, rec.k2, b['bn2'].weight, part=part)
+        q2, dgam, dbet, _ = E.bn_backward(g, rec.c2, rec.k2, b['bn2'].weight, part=part, slabs=pending)
         grads[id(b['bn2'].weight)], grads[id(b['bn2'].bias)] = dgam, dbet
         dy2 = Operand(g, tuple(rec.c2.shape), pro=L.PRO_BNBWD, x2=rec.c2, pa=q2[0], pb=q2[1], pd=q2[2])
         a1_op = Operand.affine_act(rec.c1, rec.k1[0], rec.k1[1], b['prelu'])
         g_a1, part = conv_bwd(b['c2'], a1_op, dy2, bnb=(rec.c1, rec.k1, b['prelu']))
-        q1, dgam, dbet, dsl = E.bn_backward(g_a1, rec.c1, rec.k1, b['bn1'].weight, slope=b['prelu'], part=part)
+        q1, dgam, dbet, dsl = E.bn_backward(g_a1, rec.c1, rec.k1, b['bn1'].weight, slope=b['prelu'], part=part, slabs=pending)
         grads[id(b['bn1'].weight)], grads[id(b['bn1'].bias)] = dgam, dbet
         grads[id(b['prelu'])] = dsl
         dy1 = Operand(g_a1, tuple(rec.c1.shape), pro=L.PRO_BNACT_BWD, x2=rec.c1, pa=q1[0], pb=q1[1],

@@ -211,3 +211,31 @@ def test_batchnorm_finalised_inside_the_consuming_conv(precision, monkeypatch):
             assert not torch.equal(res['1'][3][k], state[k]), k
     finally:
         E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_deferred_slab_reductions_reproduce_the_separate_launches(precision, monkeypatch):
+    """Generator backward with every weight gradient's slab sum carried by the next BatchNorm-backward finishing launch
+    (engine.PendingSlabs, the default) against the schedule with one sisr_slab_reduce_f32 launch per layer
+    (SISR_FUSE_SLABRED=0): the same sums in the same order -- every gradient bit-identical"""
+    E, mg = pkg('engine'), pkg('model_generator')
+    E.set_precision(precision)
+    try:
+        torch.manual_seed(0)
+        net = mg.Generator(3, 64, 256, [2], use_sn=True).cuda().train()
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        g = torch.Generator().manual_seed(6)
+        x = (torch.rand(2, 3, 16, 32, generator=g) * 2 - 1).cuda()
+        r = (torch.rand(2, 3, 32, 64, generator=g) * 2 - 1).cuda()
+        res = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_FUSE_SLABRED', sw)
+            net.load_state_dict(state)
+            net.zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            (net(xin) * r).sum().backward()
+            res[sw] = (xin.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()})
+        assert torch.equal(res['1'][0], res['0'][0])
+        assert all(torch.equal(res['1'][1][k], res['0'][1][k]) for k in res['1'][1])
+    finally:
+        E.set_precision('fp32')

@@ -367,6 +367,35 @@ def test_bn_backward_reductions_from_the_conv_epilogue(E, L, shape, act, storage
         E.set_precision('fp32')
 
 
+def test_bn_backward_finish_carries_a_slab_reduction(E, L):
+    """sisr_bn_bwd_finalize_slab: ONE launch finishes a BatchNorm backward from partial rows and sums the slabs of an
+    unrelated weight gradient in additional workgroups -- both results bit-identical to the two separate launches
+    (sisr_bn_bwd_finalize, sisr_slab_reduce_f32), for slab widths that do and do not fill the last workgroup"""
+    import ctypes as C
+    lib = L.lib()
+    cch, rows = 64, 231
+    g = torch.Generator().manual_seed(5)
+    part = (torch.rand(rows, 2 * cch + 1, generator=g) - 0.5).cuda()
+    x = torch.rand(4, 8, 8, cch, generator=g).cuda()
+    consts = (torch.rand(4, cch, generator=g) + 0.5).cuda()
+    gamma = (torch.rand(cch, generator=g) + 0.5).cuda()
+    slope = torch.tensor([0.25], device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    for n_slabs, stride in ((231, 36928), (7, 20), (40, 16 * 4 * 5 + 4)):
+        slab = (torch.rand(n_slabs, stride, generator=g) - 0.5).cuda()
+        want_red = torch.empty(stride, device='cuda')
+        L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), want_red.data_ptr(), n_slabs, stride, st), 'slab_reduce')
+        want = E.bn_backward(x, x, consts, gamma, slope=slope, part=part)
+        pend = E.PendingSlabs()
+        red = torch.full((stride,), float('nan'), device='cuda')
+        pend.jobs.append((slab, red, n_slabs, stride))
+        got = E.bn_backward(x, x, consts, gamma, slope=slope, part=part, slabs=pend)
+        assert pend.jobs == []
+        assert torch.equal(red, want_red)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+
+
 def _merged_stats(sp, cp):
     cnt, mean_t, m2_t = cp.double().cpu(), sp[:, 0].double().cpu(), sp[:, 1].double().cpu()
     tot = cnt.sum()

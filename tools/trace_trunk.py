@@ -17,7 +17,13 @@ t = buf.reshape(512, slots).astype(np.int64) * 10e-3
 t = t[t[:, 0] > 0]
 t0 = t[:, 0].min()
 print('%d workgroups; kernel span %.2f us; lifetime avg %.2f; start spread %.2f' % (len(t), t[:, 63].max() - t0, (t[:, 63] - t[:, 0]).mean(), (t[:, 0] - t0).max()))
-ck = (t[:, 61] - t[:, 60]) / 10e-3 / ((t[:, 63] - t[:, 0]) * 100.0)      # raw ticks / (us x 100 ticks per us)
+if prec == 'fp32':
+    cb = np.zeros(512 * 2, dtype=np.uint64)
+    assert L.sisr_cfclk_read(cb.ctypes.data_as(C.c_void_p), C.c_int(cb.size)) == 0
+    cb = cb.reshape(512, 2).astype(np.int64)[:len(t)]
+    ck = (cb[:, 1] - cb[:, 0]) / ((t[:, 63] - t[:, 0]) * 100.0)
+else:
+    ck = (t[:, 61] - t[:, 60]) / 10e-3 / ((t[:, 63] - t[:, 0]) * 100.0)      # raw ticks / (us x 100 ticks per us)
 print('in-kernel shader clock (s_memtime / s_memrealtime): median %.3f GHz' % (float(np.median(ck)) / 10.0))
 print('prologue (weights to registers / first tile staged, barrier) +%.2f' % (t[:, 4] - t[:, 0]).mean())
 for it in range(8):
@@ -34,4 +40,6 @@ for it in range(8):
         dp = lambda i, j: (t[okp, j] - t[okp, i]).mean()
         print('          producer (wave 4): issue %.2f  wait + commit %.2f  wait at barrier %.2f' % (
             dp(pb, pb + 1), dp(pb + 1, pb + 4), dp(pb + 4, pb + 5)))
+if (t[:, 1] > 0).all():
+    print('tail epilogue (after the last barrier) ends at +%.2f, role branches join at +%.2f of the lifetime' % ((t[:, 1] - t[:, 0]).mean(), (t[:, 3] - t[:, 0]).mean()))
 print('stats tail +%.2f' % (t[:, 63] - t[:, 3]).mean())
