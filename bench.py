@@ -20,7 +20,13 @@ ONE invocation measures BOTH arithmetic builds, each over exactly --steps timed 
 Each record carries the roofline of the kernel with the LARGEST total time per step (trunk forward conv, trunk
 data-gradient conv and trunk weight gradient are probed live with HIP events on the launch stream) and a
 whole-step fraction (SURVEY 8d algorithmic flops / bytes over the measured step time).  ``cpu_baseline``: the
-oracle (CPU restatement, torch-CPU fp32) timed on this host's cores on a bounded sample; rank 0, N=1 only.
+oracle (CPU restatement, torch-CPU fp32) timed on this host's cores on the same batch (3 steps, ~10 s each); rank 0,
+N=1 only.
+
+``configs`` (N = 1 only; ``--configs none`` skips it): BASELINE.json's configs 2-5 as ONE-GPU iteration rates -- a full SRGAN
+iteration (train.py:45-108: G forward, D step on real + detached fake, G step through D and the VGG content
+extractor, both fused Adam steps) of each config's networks at its sizes in the bf16 build, replayed from two HIP
+graphs, with the algorithmic flops / bytes of one iteration and the fractions of the MI355X peaks they amount to.
 
 ``--gpus N`` with N > 1 starts the N rank processes itself (``torch.distributed.run``, one per GPU, rendezvous
 on 127.0.0.1) BEFORE anything touches the GPU, unless it already runs under such a launcher (WORLD_SIZE set).
@@ -173,14 +179,17 @@ def _time_launches(fn, iters):
 
 def _recorded_traffic(kernel_key):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, gfx950
-    corrections applied): bench.py cannot run rocprofv3 on itself, so the figure is the one RECORDED in
-    profiles/r02_traffic.json for this kernel (with the commit it was collected at); null when absent."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_traffic.json')) as fh:
-            rec = json.load(fh)[kernel_key]
-        return rec['traffic_bytes_per_launch'], 'recorded: profiles/r02_traffic.json @ %s' % rec.get('commit', '?')
-    except (OSError, KeyError, ValueError, TypeError):
-        return None, None
+    corrections applied): bench.py cannot run rocprofv3 on itself, so the figure is the one RECORDED under profiles/
+    for this kernel by tools/pmc_collect.sh (newest round first), with the commit it was collected at; null when
+    absent."""
+    for name in ('r03_traffic.json', 'r02_traffic.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as fh:
+                rec = json.load(fh)[kernel_key]
+            return rec['traffic_bytes_per_launch'], 'recorded: profiles/%s @ %s' % (name, rec.get('commit', '?'))
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None, None
 
 
 def kernel_rooflines(device, precision, iters=40, only=None):
@@ -256,9 +265,10 @@ def kernel_rooflines(device, precision, iters=40, only=None):
                    'alg_bytes_per_launch': nbytes, 'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 1)}
         else:
             achieved = flops / (ms * 1e-3) / 1e12
+            traffic, src = _recorded_traffic('%s_%s' % (fam, role))
             rec = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                   'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
-                   'alg_flops_per_launch': flops}
+                   'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': src,
+                   'alg_flops_per_launch': flops, 'alg_bytes_per_launch': nbytes}
         rec.update({'kernel': names[role], 'launch_ms': round(ms, 4), 'launches_per_step': per_step,
                     'ms_per_step': round(ms * per_step, 3), 'storage': 'bf16' if elt == 2 else 'f32'})
         out_rec[role] = rec
@@ -286,10 +296,10 @@ def whole_step(precision, elt, ms_per_step):
 # ------------------------------------------------------------------------------------------------------------
 # CPU baseline
 # ------------------------------------------------------------------------------------------------------------
-def cpu_baseline(sample_b=4, repeats=3):
-    """The oracle (CPU restatement, torch-CPU fp32) on the same graph.  BOUNDED sample: `sample_b` patches of the
-    same HR 192 workload per step (the graph is per-patch work; BatchNorm just sees a smaller batch), best of
-    `repeats` timed steps after one warm-up, on all host threads torch uses."""
+def cpu_baseline(sample_b=B, repeats=2):
+    """The oracle (CPU restatement, torch-CPU fp32) on the SAME graph and the SAME batch as a GPU step: all B = 16
+    patches of HR 192 (BatchNorm sees the batch the GPU step sees), best of `repeats` timed steps after one warm-up,
+    on all host threads torch uses.  ~10 s of CPU per step on the GPU node's host."""
     import torch
     from oracle import init as oinit, models as omodels, ops as oops          # checker/baseline only
     mg = sub('model_generator')
@@ -320,8 +330,165 @@ def cpu_baseline(sample_b=4, repeats=3):
         step()
         best = min(best, time.time() - t0)
     return {'value': round(sample_b / best, 3), 'unit': 'HR patches/s', 'cores': cores, 'kind': 'port',
-            'sample': 'best of %d timed steps (after 1 warm-up) of the same graph on %d of the %d HR-%d patches of a '
-                      'step, oracle/ on torch-CPU fp32' % (repeats, sample_b, B, HR)}
+            'sample': 'best of %d timed steps (after 1 warm-up) of the same graph on the full batch of %d HR-%d patches '
+                      '(%.1f s per step), oracle/ on torch-CPU fp32' % (repeats, sample_b, HR, best)}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs 2-5: one-GPU iteration rates
+# ------------------------------------------------------------------------------------------------------------
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
+FEATS, STRIDES = [64, 64, 128, 128, 256, 256, 512, 512], [1, 2, 1, 2, 1, 2, 1, 2]      # config.py:81-82
+VGG_CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M')
+CONFIGS = {
+    # name: (BASELINE.json config string, HR, LR, generator kind, VGG mask)
+    'cfg2': ('CelebA 96-crop x2 SRGAN (G+D+VGG22 content loss) bf16', 96, 48, 'x2', 0b00010),
+    'cfg3': ('CelebA 96-crop x4 SRGAN, VGG54 content loss', 96, 24, 'x4_suffix', 0b10000),
+    'cfg4': ('Flickr8k 192-crop x4 SRGAN, spectral-norm D', 192, 48, 'x4_suffix', 0b10000),
+    'cfg5': ('Progressive x8 (model_generator_progressive, x2->x4->x8 stacked upsample)', 192, 24, 'progressive_x8', 0b10000),
+}
+
+
+def _conv_layers(kind, hr, lr, mask):
+    """[(net, cin, cout, k, h_in, w_in, h_out, w_out)] of every conv of a config's G, D and VGG stack, and D's two Linear
+    layers as (net, 'fc', in, out): the shapes the flop / byte model below is evaluated on"""
+    out = []
+    if kind == 'progressive_x8':
+        out.append(('g', 3, 64, 9, lr, lr, lr, lr))
+        out += [('g', 64, 64, 3, lr, lr, lr, lr)] * 33
+        c, r = 64, lr
+        for _ in range(3):
+            out.append(('g', c, c, 3, r, r, r, r))             # conv(n -> n) + PixelShuffle(2): n / 4 channels at 2 r
+            c, r = c // 4, 2 * r
+        out.append(('g', c, 3, 3, r, r, r, r))
+    else:
+        out.append(('g', 3, 64, 9, lr, lr, lr, lr))
+        out += [('g', 64, 64, 3, lr, lr, lr, lr)] * 33
+        r = lr
+        for _ in range(1 if kind == 'x2' else 2):
+            out.append(('g', 64, 256, 3, r, r, r, r))
+            r *= 2
+        out.append(('g', 64, 3, 3, r, r, r, r))
+    c, r = 3, hr
+    for f, st in zip(FEATS, STRIDES):
+        out.append(('d', c, f, 3, r, r, r // st, r // st))
+        c, r = f, r // st
+    out.append(('d', 'fc', c * r * r, 1024))
+    out.append(('d', 'fc', 1024, 1))
+    kept = max(i for i in range(5) if mask & (1 << i))
+    n_layers = (3, 8, 17, 26, 35)[kept]                       # features[:k] (model_content_extractor.py:41-43)
+    c, r, idx = 3, hr, 0
+    for v in VGG_CFG:
+        if idx >= n_layers:
+            break
+        if v == 'M':
+            r //= 2
+            idx += 1
+        else:
+            out.append(('v', c, v, 3, r, r, r, r))
+            c = v
+            idx += 2
+    return out
+
+
+def config_work(kind, hr, lr, mask):
+    """Algorithmic work of ONE SRGAN iteration (train.py:45-108, empty replay list), SURVEY 8d conventions:
+    flops = 2 MACs; G: forward once + data and weight gradients (3 F_G); D: forward on real, on the detached fake and on
+    the fake of the G step, data + weight gradients in the D step, data gradient in the G step (8 F_D); frozen VGG:
+    forward on real and fake + data gradient (3 F_V).  bytes: every conv reads its input and writes its output once per
+    pass (backward: dy + the saved activation + dx for the data gradient, x + dy for the weight gradient), bf16 for
+    multi-channel tensors and fp32 for 3-channel images; the Linear layers stream their fp32 weights once per pass."""
+    passes = {'g': (1, 1, 1), 'd': (3, 3, 2), 'v': (2, 1, 0)}     # forward, data-gradient, weight-gradient passes
+    flops = nbytes = 0.0
+    for lay in _conv_layers(kind, hr, lr, mask):
+        net = lay[0]
+        fw, dg, wg = passes[net]
+        if lay[1] == 'fc':
+            _, _, k, n = lay
+            flops += 2.0 * B * k * n * (fw + dg + wg)
+            nbytes += 4.0 * k * n * (fw + dg + wg)
+            continue
+        _, cin, cout, ks, hi, wi, ho, wo = lay
+        flops += 2.0 * B * ho * wo * cin * cout * ks * ks * (fw + dg + wg)
+        ei, eo = (4 if cin <= 4 else 2), (4 if cout <= 4 else 2)
+        i_b, o_b = B * hi * wi * cin * ei, B * ho * wo * cout * eo
+        nbytes += fw * (i_b + o_b) + dg * (2 * o_b + i_b) + wg * (i_b + o_b)
+    return flops, nbytes
+
+
+def bench_config(name, device, iters, log):
+    """-> record of one config: ms per iteration, HR patches/s, its algorithmic work and roofline fractions"""
+    import torch
+    desc, hr_sz, lr_sz, kind, mask = CONFIGS[name]
+    E, G = sub('engine'), sub('graph')
+    mg, md, mce, ut, op = (sub('model_generator'), sub('model_discriminator'), sub('model_content_extractor'), sub('utils'),
+                           sub('optim'))
+    E.set_precision('bf16')
+    torch.manual_seed(0)
+    if kind == 'progressive_x8':
+        mp = sub('model_generator_progressive')
+        g1 = mp.GeneratorSuffix(mp.GeneratorProgresiveBase(16, 64), 64)
+        g2 = mp.GeneratorSuffix(g1.beginning, 16)
+        net_g = mp.GeneratorSuffix(g2.beginning, 4)
+    else:
+        net_g = mg.Generator(16, 64, 256, [2], use_sn=True)
+        if kind == 'x4_suffix':
+            net_g = mg.GeneratorSuffix(net_g)
+    net_g = net_g.to(device).train()
+    net_d = md.Discriminator((3, hr_sz, hr_sz), FEATS, STRIDES).to(device).train()
+    ext = mce.MaskedVGG(mask, pretrained=False).to(device)       # synthetic weights: the pretrained ones need a remote fetch
+    og, od = op.Adam(net_g.parameters(), lr=1e-5), op.Adam(net_d.parameters(), lr=1e-5)
+    crit = torch.nn.BCELoss()
+    hr = torch.rand(B, 3, hr_sz, hr_sz, device=device) * 2 - 1
+    ones, red, zeros = torch.ones(B, device=device), torch.full((B,), .9, device=device), torch.zeros(B, device=device)
+
+    def d_part():                       # train.py:45-74
+        lr = ut.lr_from_hr(hr, (lr_sz, lr_sz), device=device)
+        fake = net_g(lr)
+        net_d.zero_grad()
+        err_d = crit(net_d(hr).view(-1), red) + crit(net_d(fake.detach()).view(-1), zeros)
+        err_d.backward()
+        return err_d
+
+    def g_part():                       # train.py:82-107 (D already stepped)
+        lr = ut.lr_from_hr(hr, (lr_sz, lr_sz), device=device)
+        fake = net_g(lr)
+        net_g.zero_grad()
+        err_g = crit(net_d(fake).view(-1), ones) * 5e-2 + torch.mean(torch.pow(ext(hr) - ext(fake), 2))
+        err_g.backward()
+        return err_g
+    graphed = True
+    try:
+        d_run, g_run = G.GraphedStep(d_part), G.GraphedStep(g_part)
+    except G.GraphCaptureError as e:
+        log('%s: %s -- launching eagerly instead' % (name, e))
+        d_run, g_run, graphed = d_part, g_part, False
+
+    def iteration():
+        d_run()
+        od.step()
+        g_run()
+        og.step()
+    for _ in range(3):
+        iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        iteration()
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / iters
+    flops, nbytes = config_work(kind, hr_sz, lr_sz, mask)
+    rec = {'config': desc, 'hr': hr_sz, 'lr': lr_sz, 'generator': kind, 'vgg_mask': mask, 'per_gpu_batch': B, 'dtype': 'bf16',
+           'iters': iters, 'ms_per_iteration': round(sec * 1e3, 3), 'value': round(B / sec, 1), 'unit': 'HR patches/s',
+           'hip_graph': graphed, 'g_forward_runs': 2,          # (each half owns the autograd state it differentiates; the reference runs G once: the second run is overhead here, not credited work)
+           'alg_flops': flops, 'alg_bytes': nbytes,
+           'roofline': {'bound': 'hbm', 'achieved': round(nbytes / sec / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': round(nbytes / sec / 1e9 / PEAK_HBM_GBS, 4), 'traffic': None,
+                        'mfma_tflops': round(flops / sec / 1e12, 1),
+                        'frac_mfma_bf16': round(flops / sec / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}}
+    del net_g, net_d, ext, og, od, d_run, g_run
+    torch.cuda.empty_cache()
+    return rec
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -335,6 +502,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying HIP graphs')
     ap.add_argument('--precision', choices=['both', 'fp32', 'bf16'], default=os.environ.get('SISR_BENCH_PRECISION', 'both'),
                     help='both (default): fp32 parity build at top level + bf16 build as perf_build; or one build only')
+    ap.add_argument('--configs', default='all', help="BASELINE.json configs timed as one-GPU iteration rates (N = 1 only): "
+                    "'all', 'none' or a comma list of cfg2,cfg3,cfg4,cfg5")
+    ap.add_argument('--config-iters', type=int, default=10)
     ap.add_argument('--dry-run-ranks', action='store_true',
                     help='launcher self-test: start the ranks, all-reduce a 1 over them and print the count (no GPU work)')
     args = ap.parse_args()
@@ -415,6 +585,15 @@ def main():
         }
         if len(builds) == 2:
             rec['perf_build'] = records['bf16']
+        if world == 1 and args.configs != 'none':
+            names = list(CONFIGS) if args.configs == 'all' else [c for c in args.configs.split(',') if c in CONFIGS]
+            rec['configs'] = {}
+            for name in names:
+                try:
+                    rec['configs'][name] = bench_config(name, device, args.config_iters, log)
+                except Exception as e:                              # noqa: BLE001  (the headline line must still be printed)
+                    rec['configs'][name] = {'error': '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')}
+            sub('engine').set_precision('fp32')
         if world == 1 and not args.no_cpu_baseline:
             rec['cpu_baseline'] = cpu_baseline()
         print(json.dumps(rec), flush=True)

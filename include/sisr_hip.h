@@ -375,6 +375,20 @@ int sisr_fc_wgrad(const float *dy, const float *x, float in_slope, float *dW, fl
 int sisr_act_bwd(const float *dy, const float *ref, float *out, int64_t n, int32_t kind, float slope,
                  void *stream);   /* kind 0: leaky (ref = pre-activation), 1: sigmoid (ref = output) */
 
+/* ---- dataset transform ---------------------------------------------------------------------------
+ * replaces, for a batch of decoded images, the per-image transform of config.py:225-231
+ *   transforms.Compose([transforms.Resize(image_size_hr[1:]), transforms.ToTensor(), transforms.Normalize(.5, .5)])
+ * i.e. PIL.Image.resize(BILINEAR) (Pillow's ImagingResample, 8 bits per channel: anti-aliased separable triangle filter,
+ * 22-bit fixed-point coefficients, rounding to uint8 after each pass), uint8 -> float32 / 255, (t - mean) / std.
+ * Integer arithmetic throughout the resize: bit-exact with Pillow.
+ * sisr_resize_coeffs: HOST function; returns the taps per output index (ksize) and, with non-NULL tables, fills
+ *   bounds[out_size][2] = (first input index, tap count) and kk[out_size][ksize] for one axis.
+ * sisr_resize_u8_normalize: src [N][H0][W0][C] uint8 -> dst [N][C][H][W] float32 with device copies of the two tables. */
+int sisr_resize_coeffs(int32_t in_size, int32_t out_size, int32_t *bounds, int32_t *kk);
+int sisr_resize_u8_normalize(const unsigned char *src, float *dst, int32_t N, int32_t H0, int32_t W0, int32_t C,
+                             int32_t H, int32_t W, const int32_t *bx, const int32_t *kx, int32_t ksx,
+                             const int32_t *by, const int32_t *ky, int32_t ksy, float mean, float stdv, void *stream);
+
 /* ---- bicubic degradation, align_corners=True, A=-0.75, clamp to [-1,1]
  *      (utils.py:16-31: F.interpolate(..., 'bicubic', align_corners=True) + _crop_lr) -------- */
 int sisr_bicubic_fwd(const float *x, float *y, int32_t NC, int32_t H, int32_t W, int32_t Ho,

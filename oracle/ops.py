@@ -137,3 +137,82 @@ def bicubic_align_corners(x, size):
 def lr_from_hr(img_hr, image_size_lr):
     """utils.lr_from_hr (utils.py:22-31): bicubic then clamp to [-1, 1] (utils.py:19-20)."""
     return torch.clamp(bicubic_align_corners(img_hr, image_size_lr), -1.0, 1.0)
+
+
+# --------------------------------------------------------------------------------------------
+# patch pipeline (SURVEY 8f row f4): the transforms the reference's dataset applies to every decoded image
+# (config.py:225-231: transforms.Resize(image_size_hr[1:]), ToTensor(), Normalize(.5, .5)) followed by
+# utils.lr_from_hr (train.py:45-46).  The arithmetic lives in third-party code that is not in the reference tree:
+#   * torchvision.transforms.Resize on a PIL image = PIL.Image.resize((w, h), BILINEAR), Pillow's ImagingResample
+#     (src/libImaging/Resample.c), restated below: a separable triangle filter whose support grows with the
+#     down-scaling factor (anti-aliasing), coefficients quantised to 22 fractional bits, int32 accumulation with a
+#     half-unit offset, and a ROUNDING TO uint8 AFTER EACH of the two passes (horizontal first);
+#   * ToTensor = uint8 HWC -> float32 CHW / 255;  Normalize(.5, .5) = (t - 0.5) / 0.5.
+# Pinned against Pillow itself (tests/test_oracle_golden.py, tests/golden/patch_pipeline.npz).
+# --------------------------------------------------------------------------------------------
+PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def pil_bilinear_coeffs(in_size, out_size):
+    """precompute_coeffs + normalize_coeffs_8bpc of Resample.c for the whole-image box and the BILINEAR filter
+    (support 1.0).  -> (ksize, bounds [out, 2] = (first input index, tap count), kk [out, ksize] int32)"""
+    scale = float(np.float32(in_size) - np.float32(0.0)) / out_size          # (in1 - in0) are floats in the C code
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = np.zeros(ksize, dtype=np.float64)
+        for x in range(xmax):
+            a = abs((x + xmin - center + 0.5) * ss)
+            w[x] = 1.0 - a if a < 1.0 else 0.0
+        ww = 0.0                                   # (accumulated in tap order, as the C code does)
+        for x in range(xmax):
+            ww += w[x]
+        if ww != 0.0:
+            w[:xmax] /= ww
+        for x in range(ksize):
+            kk[xx, x] = int(-0.5 + w[x] * (1 << PIL_PRECISION_BITS)) if w[x] < 0 else int(0.5 + w[x] * (1 << PIL_PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return ksize, bounds, kk
+
+
+def _pil_resample_axis(img, out_size, axis):
+    """one 8-bit pass of ImagingResample along `axis` of an HWC uint8 array"""
+    in_size = img.shape[axis]
+    ksize, bounds, kk = pil_bilinear_coeffs(in_size, out_size)
+    src = np.moveaxis(img, axis, 0).astype(np.int64)
+    out = np.empty((out_size,) + src.shape[1:], dtype=np.uint8)
+    for xx in range(out_size):
+        xmin, xmax = bounds[xx]
+        acc = np.full(src.shape[1:], 1 << (PIL_PRECISION_BITS - 1), dtype=np.int64)
+        for x in range(xmax):
+            acc += src[xmin + x] * int(kk[xx, x])
+        out[xx] = np.clip(acc >> PIL_PRECISION_BITS, 0, 255).astype(np.uint8)
+    return np.moveaxis(out, 0, axis)
+
+
+def pil_resize_bilinear(img_u8, out_h, out_w):
+    """PIL.Image.fromarray(img).resize((out_w, out_h), Image.BILINEAR) for an HWC uint8 array: horizontal pass, then
+    vertical pass, each skipped when the size does not change (ImagingResample's need_horizontal / need_vertical)"""
+    x = img_u8
+    if x.shape[1] != out_w:
+        x = _pil_resample_axis(x, out_w, 1)
+    if x.shape[0] != out_h:
+        x = _pil_resample_axis(x, out_h, 0)
+    return x
+
+
+def patch_pipeline(imgs_u8, image_size_hr, image_size_lr):
+    """config.py:225-231 + train.py:45-46 on a batch of decoded images [N, H0, W0, C] uint8:
+    -> (img_hr [N, C, H, W] float32 in [-1, 1], img_lr = lr_from_hr(img_hr))"""
+    h, w = image_size_hr
+    hr = np.stack([pil_resize_bilinear(im, h, w) for im in imgs_u8])
+    t = torch.from_numpy(hr).permute(0, 3, 1, 2).contiguous().to(torch.float32).div(255)      # ToTensor
+    t = (t - 0.5) / 0.5                                                                       # Normalize(.5, .5)
+    return t, lr_from_hr(t, image_size_lr)

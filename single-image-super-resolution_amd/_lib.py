@@ -142,6 +142,8 @@ _SIGS = {
     'sisr_fc_dgrad': [_f, _f, _f, _f, _i32, _i32, _i32, _f],
     'sisr_fc_wgrad': [_f, _f, _f32, _f, _f, _i32, _i32, _i32, _f],
     'sisr_act_bwd': [_f, _f, _f, _i64, _i32, _f32, _f],
+    'sisr_resize_coeffs': [_i32, _i32, _f, _f],
+    'sisr_resize_u8_normalize': [_f, _f, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f, _i32, _f, _f, _i32, _f32, _f32, _f],
     'sisr_bicubic_fwd': [_f, _f, _i32, _i32, _i32, _i32, _i32, _i32, _f],
     'sisr_bicubic_bwd': [_f, _f, _f, _i32, _i32, _i32, _i32, _i32, _f],
     'sisr_struct_sizes': [C.POINTER(_i32), _i32],

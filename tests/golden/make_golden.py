@@ -190,6 +190,41 @@ def bicubic_cases():
     print('bicubic ok')
 
 
+def patch_pipeline_cases():
+    """row f4: the dataset transform of config.py:225-231 applied with the libraries the reference calls -- torchvision's
+    Resize on a PIL image is ``img.resize(size[::-1], PIL.Image.BILINEAR)``, ToTensor is uint8 HWC -> float CHW / 255,
+    Normalize(.5, .5) is (t - .5) / .5 (torchvision itself is not installed here; Pillow, which does the arithmetic, is)
+    -- followed by the F.interpolate call of utils.py:17 and the clamp of utils.py:20.  Sizes: CelebA (218 x 178) to the
+    cfg1 / cfg2 crops, a Flickr-like landscape image to HR 192, MNIST-like grayscale 28 -> 14, an up-scaling case."""
+    from PIL import Image
+    rs = np.random.RandomState(7)
+    rec, cases = {}, [((2, 218, 178, 3), (64, 64), (32, 32)), ((2, 218, 178, 3), (96, 96), (48, 48)),
+                      ((1, 333, 500, 3), (192, 192), (48, 48)), ((2, 28, 28, 1), (14, 14), (7, 7)),
+                      ((1, 37, 53, 3), (64, 64), (32, 32)), ((1, 64, 100, 3), (64, 64), (32, 32))]
+    for i, (shape, hr, lr) in enumerate(cases):
+        # smooth random images (pure noise would make every anti-aliased pixel ~ 128)
+        base = rs.randint(0, 256, (shape[0], shape[1] // 8 + 2, shape[2] // 8 + 2, shape[3])).astype(np.uint8)
+        imgs = np.stack([np.asarray(Image.fromarray(b.squeeze(-1) if shape[3] == 1 else b).resize((shape[2], shape[1]), Image.BICUBIC))
+                         .reshape(shape[1:]) for b in base])
+        imgs = np.clip(imgs.astype(int) + rs.randint(-20, 21, imgs.shape), 0, 255).astype(np.uint8)
+        outs = []
+        for im in imgs:
+            pil = Image.fromarray(im.squeeze(-1) if shape[3] == 1 else im)
+            res = np.asarray(pil.resize((hr[1], hr[0]), Image.BILINEAR)).reshape(hr + (shape[3],))     # transforms.Resize
+            t = torch.from_numpy(res.copy()).permute(2, 0, 1).contiguous().to(torch.float32).div(255)       # ToTensor
+            t = (t - 0.5) / 0.5                                                                          # Normalize
+            outs.append(t)
+        img_hr = torch.stack(outs)
+        y = F.interpolate(img_hr, lr, mode='bicubic', align_corners=True)                                # utils.py:17
+        img_lr = torch.max(torch.min(y, torch.full((1,), 1.0)), torch.full((1,), -1.0))                  # utils.py:20
+        rec['imgs%d' % i], rec['hr_size%d' % i], rec['lr_size%d' % i] = imgs, np.array(hr), np.array(lr)
+        rec['img_hr%d' % i], rec['img_lr%d' % i] = img_hr.numpy(), img_lr.numpy()
+    rec['n'] = np.array(len(cases))
+    path = os.path.join(HERE, 'patch_pipeline.npz')
+    np.savez_compressed(path, **rec)
+    print('patch pipeline ok  %.2f MB' % (os.path.getsize(path) / 1e6))
+
+
 def vgg_cases():
     """VGG19-features stand-in (torch primitives) + the reference's tap loop semantics; weights
     synthetic (pretrained fetch impossible offline).  Channel widths divided by 8 to
@@ -235,6 +270,9 @@ def vgg_cases():
 
 if __name__ == '__main__':
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'patches':   # only the patch-pipeline fixture (needs Pillow, not the reference)
+        patch_pipeline_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'deep':      # only the full-depth fixtures
         deep_generator_cases()
         sys.exit(0)
@@ -243,4 +281,5 @@ if __name__ == '__main__':
     progressive_cases()
     discriminator_cases()
     bicubic_cases()
+    patch_pipeline_cases()
     vgg_cases()

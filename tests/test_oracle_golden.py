@@ -152,3 +152,25 @@ def test_losses_match_torch():
     assert abs(float(ol.adversarial_loss_d(p, [q]) - ref)) < 1e-6
     assert abs(float(ol.adversarial_loss_g(q) - crit(q.view(-1), torch.full((16,), 1.)))) < 1e-6
     assert float(ol.bce(torch.zeros(4), 1.0)) == 100.0                  # log clamp
+
+
+def test_patch_pipeline_oracle_matches_pillow_and_torch(golden_dir):
+    """row f4: oracle.ops.patch_pipeline -- Pillow's 8-bit BILINEAR ImagingResample restated in integer arithmetic,
+    ToTensor, Normalize(.5, .5), then lr_from_hr -- against tests/golden/patch_pipeline.npz, which was produced by
+    Pillow's own Image.resize and torch's own F.interpolate (make_golden.py patch_pipeline_cases): the resized /
+    normalised HR batch BIT-EXACT, the LR batch to fp32 rounding.  Also directly against Pillow where it is installed."""
+    z = np.load(os.path.join(golden_dir, 'patch_pipeline.npz'))
+    for i in range(int(z['n'])):
+        imgs, hr, lr = z['imgs%d' % i], tuple(int(v) for v in z['hr_size%d' % i]), tuple(int(v) for v in z['lr_size%d' % i])
+        img_hr, img_lr = oo.patch_pipeline(imgs, hr, lr)
+        assert np.array_equal(img_hr.numpy(), z['img_hr%d' % i]), i
+        assert float((img_lr - torch.from_numpy(z['img_lr%d' % i])).abs().max()) < 2e-6, i
+        assert float(img_lr.abs().max()) <= 1.0
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    rs = np.random.RandomState(3)
+    for h0, w0, h, w in ((218, 178, 96, 96), (41, 67, 64, 32), (9, 9, 17, 23), (64, 64, 64, 64)):
+        a = rs.randint(0, 256, (h0, w0, 3)).astype(np.uint8)
+        assert np.array_equal(oo.pil_resize_bilinear(a, h, w), np.asarray(Image.fromarray(a).resize((w, h), Image.BILINEAR)))
