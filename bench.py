@@ -296,6 +296,31 @@ def whole_step(precision, elt, ms_per_step):
 # ------------------------------------------------------------------------------------------------------------
 # CPU baseline
 # ------------------------------------------------------------------------------------------------------------
+def _host_cpus():
+    """CPUs this process may actually use: the cgroup quota when there is one (a GPU box gives a container a share of
+    the host's cores), else the affinity mask, else os.cpu_count()"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith('cpu.max'):
+                if parts[0] != 'max':
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fh2:
+                        n = min(n, max(1, q // int(fh2.read().split()[0])))
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    return n
+
+
 def cpu_baseline(sample_b=B, repeats=2):
     """The oracle (CPU restatement, torch-CPU fp32) on the SAME graph and the SAME batch as a GPU step: all B = 16
     patches of HR 192 (BatchNorm sees the batch the GPU step sees), best of `repeats` timed steps after one warm-up,
@@ -311,7 +336,8 @@ def cpu_baseline(sample_b=B, repeats=2):
         state[k].requires_grad_(True)
     opt = torch.optim.Adam([state[k] for k in pk], lr=1e-5, betas=(0.9, 0.999))
     hr = oinit.synth_input((sample_b, 3, HR, HR), 0)
-    cores = torch.get_num_threads()
+    cores = _host_cpus()
+    torch.set_num_threads(cores)          # (os.cpu_count() of a container is the host's: 128 threads on a 16-CPU share thrash)
 
     def step():
         lr = oops.lr_from_hr(hr, (LR, LR))

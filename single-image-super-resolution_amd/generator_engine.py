@@ -209,8 +209,8 @@ def run_backward(sv, grad_out, need_dx, sink=None, params=()):
     # ---- end conv + tanh (or, for forward_no_end, the NCHW -> NHWC change of the incoming gradient) --------
     ho, wo = sv.out.shape[2], sv.out.shape[3]
     if topo.end is None:
-        if not topo.stages:
-            raise NotImplementedError('backward of forward_no_end without an upscale stage')
+        # no `end` conv: the incoming gradient is that of the last upscale stage's activation -- or, with no stage at all
+        # (the bare trunk, model_generator_progressive.py:40-44), of the trunk's BatchNorm output itself
         g = E.nchw_to_nhwc(grad_out, sv.out.shape[1] * ho * wo, n, ho, wo, sv.out.shape[1])
     else:
         dy = Operand(grad_out, (n, ho, wo, sv.out.shape[1]), pro=L.PRO_TANH_BWD, mode=L.X_NCHW, x2=sv.out)

@@ -100,7 +100,12 @@ class GraphedStep:
         if self._via_worker and dev not in _TRIGGER:
             _TRIGGER[dev] = (torch.zeros(1, device='cuda:%d' % dev, requires_grad=True), torch.ones(1, device='cuda:%d' % dev))
         from . import engine as E
-        side = torch.cuda.Stream(device=dev)
+        # warm-up on THE capture stream of the device (not on a stream of its own): a parameter's AccumulateGrad node runs
+        # on the stream it was created on and lives as long as anything references the graph behind it, so warm-ups of
+        # two GraphedSteps that share parameters (the D step and the G step both accumulate into the discriminator) on
+        # two different side streams leave nodes behind whose stream is not the capture stream -- autograd then warns
+        # ("AccumulateGrad node's stream does not match") and inserts cross-stream waits into the capture
+        side = _capture_stream(dev)
         side.wait_stream(torch.cuda.current_stream())
         per_run = 0
         with torch.cuda.stream(side):

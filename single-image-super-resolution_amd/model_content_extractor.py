@@ -45,6 +45,62 @@ def _vgg19_feature_modules(n_layers, width_div=1):
     return mods[:n_layers]
 
 
+class _VGGPrefix(nn.Sequential):
+    """``vgg19.features[:n]`` as the reference's vgg_4conv_1maxPool returns it: a frozen nn.Sequential (state_dict keys
+    ``<i>.weight|bias``) whose forward gives the NCHW feature map behind its last layer, here a ReLU"""
+
+    def _program(self):
+        if getattr(self, '_prog', None) is None:
+            convs, pool_pending = [], False
+            mods = list(self)
+            last_conv = max(i for i, m in enumerate(mods) if isinstance(m, Conv2d))
+            for i, m in enumerate(mods):
+                if isinstance(m, Conv2d):
+                    convs.append(dict(ref=ConvRef(m), pool_before=pool_pending, tap=0 if i == last_conv else None))
+                    pool_pending = False
+                elif m.what.startswith('MaxPool'):
+                    pool_pending = True
+            assert not pool_pending and last_conv == len(mods) - 2          # ... conv, ReLU
+            object.__setattr__(self, '_prog', VE.Program(convs, 1, last_tap_relu=True))
+        return self._prog
+
+    def forward(self, x):
+        n, _, h, w = x.shape
+        pools = sum(1 for m in self if not isinstance(m, Conv2d) and m.what.startswith('MaxPool'))
+        cout = [m for m in self if isinstance(m, Conv2d)][-1].weight.shape[0]
+        return VE.vgg_apply(self._program(), x).view(n, cout, h >> pools, w >> pools)
+
+
+def vgg_4conv_1maxPool(pretrained=True):
+    """model_content_extractor.py:16-31: the VGG19 feature map in front of the second MaxPool -- ``features[:9]`` (conv1_1,
+    conv1_2, pool, conv2_1, conv2_2, each conv with its ReLU), frozen, shape (B, 128, H/2, W/2).  Weights as for MaskedVGG:
+    the torchvision checkpoint (or SISR_VGG19_WEIGHTS), an error when neither is available, seeded default initialisation
+    only with an explicit ``pretrained=False``."""
+    gen_state = torch.random.get_rng_state()
+    torch.manual_seed(1234)
+    net = _VGGPrefix(*_vgg19_feature_modules(9))
+    torch.random.set_rng_state(gen_state)
+    if pretrained:
+        path = os.environ.get('SISR_VGG19_WEIGHTS')
+        try:
+            if path:
+                sd = torch.load(path, map_location='cpu')
+                sd = {k[len('features.'):]: v for k, v in sd.items() if k.startswith('features.')} or sd
+                sd = {k: v for k, v in sd.items() if int(k.split('.')[0]) < 9}
+            else:
+                import torchvision.models as models
+                sd = models.vgg19(pretrained=True).features[:9].state_dict()
+            net.load_state_dict(sd, strict=True)
+        except Exception as e:                                  # noqa: BLE001
+            raise RuntimeError('vgg_4conv_1maxPool(pretrained=True): the VGG19 weights could not be loaded (%s: %s); the '
+                               'reference fails here too (model_content_extractor.py:19)' % (type(e).__name__, e)) from e
+    net.eval()
+    net.requires_grad = False
+    for param in net.parameters():
+        param.requires_grad = False
+    return net
+
+
 class MaskedVGG(nn.Module):
     """concatenates the VGG19 feature maps taken right before the MaxPools whose mask bit is set;
     output shape (B, -1) (model_content_extractor.py:33-60)."""

@@ -32,7 +32,9 @@ class GeneratorProgresiveBase(nn.Module):
         return t
 
     def forward(self, x):
-        raise NotImplementedError('the bare trunk is scheduled through GeneratorSuffix on the MI355X path')
+        """model_generator_progressive.py:40-44: first conv + PReLU, the residual blocks, conv + BatchNorm -- the trunk's
+        n_features-channel output (NCHW), no long skip, no upscale stage"""
+        return GE.generator_apply(self._topology(), self, x)
 
 
 class _Beginning(nn.Sequential):
@@ -45,7 +47,9 @@ class _Beginning(nn.Sequential):
         return t
 
     def forward(self, x):
-        raise NotImplementedError('scheduled through GeneratorSuffix on the MI355X path')
+        """the Sequential itself (what the next GeneratorSuffix wraps as its prefix, model_generator_progressive.py:73-76):
+        prefix, conv, PixelShuffle(2), PReLU -> the activated n_features / 4 channels at twice the resolution (NCHW)"""
+        return GE.generator_apply(self._topology(), self, x)
 
 
 class GeneratorSuffix(nn.Module):

@@ -18,8 +18,11 @@ from .engine import Operand
 class Program:
     """convs: list of dicts {ref, pool_before, tap: None | index into the tap list}"""
 
-    def __init__(self, convs, n_taps):
+    def __init__(self, convs, n_taps, last_tap_relu=False):
         self.convs, self.n_taps = convs, n_taps
+        # MaskedVGG cuts the stack right after a conv, so its last tap is pre-activation; vgg_4conv_1maxPool keeps the ReLU
+        # behind its last conv (features[:9]): its single tap is post-ReLU
+        self.last_tap_relu = last_tap_relu
         self._cache = {}
 
     def prepared(self, n, h, w):
@@ -64,7 +67,7 @@ def run_forward(prog, x):
     feat = torch.empty((n, total), dtype=torch.float32, device=x.device)
     off, sv.tap_off = 0, {}
     for t, j in enumerate(taps):
-        last = t == len(taps) - 1
+        last = t == len(taps) - 1 and not prog.last_tap_relu
         E.nhwc_to_nchw(sv.c[j], feat[:, off:], total, slope=1.0 if last else 0.0)
         sv.tap_off[j] = (off, last)
         off += sizes[t]

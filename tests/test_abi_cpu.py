@@ -112,6 +112,84 @@ def test_shape_specific_kernels_claim_exactly_their_descriptors(monkeypatch):
     assert lib.sisr_conv2d_toimage_f32_eligible(f3) == 0 and lib.sisr_wgrad_toimage_f32_eligible(g3) == 0
 
 
+def test_trunk_kernels_claim_exactly_their_descriptors(monkeypatch):
+    """Host-side dispatch rules of the persistent trunk kernels (pure host code): sisr_conv2d_trunk_eligible returns
+    1 (forward role) / 2 (data-gradient role) only for 3x3 64 -> 64 bf16 NHWC descriptors on 8 x 16 tile grids, and for
+    the UPSCALE variant (Cout 256 stored through PixelShuffle(2), model_generator.py:45-46) only without the fusions that
+    variant has no code for -- statistics, residual, fused BatchNorm reductions, skip-sum prologue, deferred BatchNorm
+    finalisation: each of those must send the descriptor to the generic kernel, not into a kernel that would ignore it
+    (and the statistics row count sisr_conv2d_bf16_parts must follow the kernel that actually runs: ADVICE r2)."""
+    E, L = _pkg('engine'), _pkg('_lib')
+    lib = L.lib()
+    for v in ('SISR_TRUNK', 'SISR_TRUNK_UP', 'SISR_PERSIST_MAX_WG'):
+        monkeypatch.delenv(v, raising=False)
+    E.set_precision('bf16')
+    try:
+        one = 1                                                    # (any non-null pointer value: eligibility only)
+        f, d, _, kinds = E.ConvGeom(64, 64, 3, 1, 1).plans(16, 96, 96)
+        assert kinds[0] and kinds[1]
+        f = L.ConvDesc.from_buffer_copy(f)
+        f.x1 = f.wpk = f.y = one
+        f.x_bf16 = f.y_bf16 = 1
+        assert lib.sisr_conv2d_trunk_eligible(f) == 1
+        f.stat_part = f.cnt_part = one
+        assert lib.sisr_conv2d_trunk_eligible(f) == 1 and lib.sisr_conv2d_bf16_parts(f) <= 256     # one row per workgroup
+        f.y_bf16 = 0
+        assert lib.sisr_conv2d_trunk_eligible(f) == 0 and lib.sisr_conv2d_bf16_parts(f) == f.plan.n_tiles
+        f.y_bf16, f.epi_act = 1, L.EPI_TANH
+        assert lib.sisr_conv2d_trunk_eligible(f) == 0
+        f.epi_act, f.pro_mode = 0, L.PRO_RES_AFFINE
+        assert lib.sisr_conv2d_trunk_eligible(f) == 0              # skip-sum prologue without its operands
+        f.x2 = f.x_out = f.pa = f.pd = one
+        assert lib.sisr_conv2d_trunk_eligible(f) == 1
+        dd = L.ConvDesc.from_buffer_copy(d)
+        dd.x1 = dd.x2 = dd.wpk = dd.y = dd.pa = dd.pb = dd.pd = one
+        dd.x_bf16 = dd.y_bf16 = 1
+        dd.pro_mode = L.PRO_BNBWD
+        assert lib.sisr_conv2d_trunk_eligible(dd) == 2
+        dd.bias = one
+        assert lib.sisr_conv2d_trunk_eligible(dd) == 0             # the data-gradient role has no bias
+        ragged = L.ConvDesc.from_buffer_copy(E.ConvGeom(64, 64, 3, 1, 1).plans(2, 20, 48)[0])
+        ragged.x1 = ragged.wpk = ragged.y = one
+        ragged.x_bf16 = ragged.y_bf16 = 1
+        assert lib.sisr_conv2d_trunk_eligible(ragged) == 0         # H % 8 != 0
+        # ---- the upscale variant
+        u = L.ConvDesc.from_buffer_copy(E.ConvGeom(64, 256, 3, 1, 1, shuffle2=True).plans(16, 96, 96)[0])
+        u.x1 = u.wpk = u.y = one
+        u.x_bf16 = u.y_bf16 = 1
+        assert u.y_mode == L.Y_SHUFFLE2 and lib.sisr_conv2d_trunk_eligible(u) == 1
+        for field in ('stat_part', 'res', 'bnb_part', 'fin_stat'):
+            v = L.ConvDesc.from_buffer_copy(u)
+            setattr(v, field, one)
+            assert lib.sisr_conv2d_trunk_eligible(v) == 0, field
+            if field == 'stat_part':                               # ... and its statistics are sized for the generic kernel
+                v.cnt_part = one
+                assert lib.sisr_conv2d_bf16_parts(v) == v.plan.n_tiles
+        v = L.ConvDesc.from_buffer_copy(u)
+        v.y_mode = L.Y_NHWC
+        assert lib.sisr_conv2d_trunk_eligible(v) == 0              # Cout 256 WITHOUT the shuffled store
+        v = L.ConvDesc.from_buffer_copy(u)
+        v.pro_mode = L.PRO_RES_AFFINE
+        v.x2 = v.x_out = v.pa = v.pd = one
+        assert lib.sisr_conv2d_trunk_eligible(v) == 0
+        v = L.ConvDesc.from_buffer_copy(u)
+        v.pro_mode = L.PRO_BNBWD                                   # a data-gradient prologue on the 256-cout forward variant
+        v.x2 = v.pa = v.pb = v.pd = one
+        assert lib.sisr_conv2d_trunk_eligible(v) == 0
+        monkeypatch.setenv('SISR_TRUNK_UP', '0')
+        assert lib.sisr_conv2d_trunk_eligible(u) == 0 and lib.sisr_conv2d_trunk_eligible(f) == 1
+        monkeypatch.setenv('SISR_TRUNK', '0')
+        assert lib.sisr_conv2d_trunk_eligible(f) == 0
+        # SISR_PERSIST_MAX_WG caps the grid of every persistent kernel (the multi-tile test knob)
+        monkeypatch.delenv('SISR_TRUNK')
+        monkeypatch.delenv('SISR_TRUNK_UP')
+        f.pro_mode, f.x2, f.x_out = L.PRO_NONE, None, None
+        monkeypatch.setenv('SISR_PERSIST_MAX_WG', '5')
+        assert lib.sisr_conv2d_bf16_parts(f) <= 5
+    finally:
+        E.set_precision('fp32')
+
+
 def test_resize_coefficient_tables_match_the_oracle():
     """sisr_resize_coeffs is a HOST function (Pillow's precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR filter):
     its tables equal the oracle's restatement entry for entry -- down-scaling (anti-aliased, wide support), up-scaling,

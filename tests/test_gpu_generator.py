@@ -239,3 +239,54 @@ def test_deferred_slab_reductions_reproduce_the_separate_launches(precision, mon
         assert all(torch.equal(res['1'][1][k], res['0'][1][k]) for k in res['1'][1])
     finally:
         E.set_precision('fp32')
+
+
+def test_progressive_trunk_and_beginning_are_callable_like_the_references():
+    """model_generator_progressive.py:40-44 and :52-56: GeneratorProgresiveBase.forward (the bare trunk: first conv + PReLU,
+    blocks, conv + BatchNorm; no long skip, no upscale stage) and the ``beginning`` Sequential a suffix is stacked on
+    (prefix, conv, PixelShuffle(2), PReLU) are nn.Modules one can call: outputs and every gradient against the oracle's
+    layers"""
+    from oracle import models as om, ops as oo
+    mp = pkg('model_generator_progressive')
+    torch.manual_seed(0)
+    g0 = mp.GeneratorProgresiveBase(2, n_features=16)
+    g1 = mp.GeneratorSuffix(g0, n_features=16)
+    state = {k: v.detach().clone() for k, v in g1.state_dict().items()}
+    g1 = g1.cuda().train()
+    x0 = torch.rand(2, 3, 16, 16, generator=torch.Generator().manual_seed(4)) * 2 - 1
+
+    def oracle(upto):
+        st = {k: v.clone() for k, v in state.items()}
+        for k in om.param_keys(st):
+            st[k].requires_grad_(True)
+        xr = x0.clone().requires_grad_(True)
+        c = om._Ctx(st, True)
+        base = 'beginning.0.'
+        t = c.prelu(base + 'first_layers.1', c.conv(base + 'first_layers.0', xr, padding=4))
+        for i in range(2):
+            b = base + 'block_list.%d.layers.' % i
+            r_ = t
+            t = c.bn(b + '4', c.conv(b + '3', c.prelu(b + '2', c.bn(b + '1', c.conv(b + '0', t)))))
+            t = r_ + t
+        t = c.bn(base + 'block_list_end.1', c.conv(base + 'block_list_end.0', t))
+        if upto == 'beginning':
+            t = c.prelu('beginning.3', oo.pixel_shuffle(c.conv('beginning.1', t), 2))
+        return st, xr, t
+
+    for upto, module, shape in (('trunk', g0, (2, 16, 16, 16)), ('beginning', g1.beginning, (2, 4, 32, 32))):
+        g1.load_state_dict(state)
+        g1.zero_grad(set_to_none=True)
+        x = x0.cuda().requires_grad_(True)
+        y = module(x)
+        assert tuple(y.shape) == shape
+        st, xr, yr = oracle(upto)
+        assert rel_err(y.detach().cpu(), yr.detach()) < TOL
+        r = torch.rand(yr.shape, generator=torch.Generator().manual_seed(5)) - 0.5
+        (yr * r).sum().backward()
+        (y * r.cuda()).sum().backward()
+        assert rel_err(x.grad.cpu(), xr.grad) < TOL
+        got = {k: p.grad.detach().cpu() for k, p in g1.named_parameters() if p.grad is not None}
+        ref = {k: st[k].grad for k in got}
+        assert grads_close(got, ref, TOL) == [], upto
+        assert all(('end.' in k or (upto == 'trunk' and k.startswith(('beginning.1', 'beginning.3')))) == (p.grad is None)
+                   for k, p in g1.named_parameters())

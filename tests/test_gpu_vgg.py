@@ -52,3 +52,33 @@ def test_masked_vgg_full_width_vs_oracle():
         (fr * r).sum().backward()
         (f * r.cuda()).sum().backward()
         assert rel_err(x.grad.cpu(), xr.grad) < TOL
+
+
+def test_vgg_4conv_1maxpool_matches_torch_primitives():
+    """model_content_extractor.vgg_4conv_1maxPool (model_content_extractor.py:16-31): ``vgg19.features[:9]`` -- conv, ReLU,
+    conv, ReLU, MaxPool, conv, ReLU, conv, ReLU -- frozen, output (B, 128, H/2, W/2) post-ReLU; forward and input gradient
+    against the same stack of torch primitives with the same (seeded) weights; state_dict keys as torchvision's Sequential"""
+    import torch.nn.functional as F
+    mce = pkg('model_content_extractor')
+    net = mce.vgg_4conv_1maxPool(pretrained=False)
+    assert list(net.state_dict()) == ['0.weight', '0.bias', '2.weight', '2.bias', '5.weight', '5.bias', '7.weight', '7.bias']
+    assert all(not p.requires_grad for p in net.parameters()) and not net.training
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    x0 = torch.rand(2, 3, 32, 48, generator=torch.Generator().manual_seed(8)) * 2 - 1
+    x = x0.cuda().requires_grad_(True)
+    y = net(x)
+    assert tuple(y.shape) == (2, 128, 16, 24)
+    xr = x0.clone().requires_grad_(True)
+    t = F.relu(F.conv2d(xr, sd['0.weight'], sd['0.bias'], padding=1))
+    t = F.relu(F.conv2d(t, sd['2.weight'], sd['2.bias'], padding=1))
+    t = F.max_pool2d(t, 2, 2)
+    t = F.relu(F.conv2d(t, sd['5.weight'], sd['5.bias'], padding=1))
+    yr = F.relu(F.conv2d(t, sd['7.weight'], sd['7.bias'], padding=1))
+    assert rel_err(y.detach().cpu(), yr.detach()) < TOL
+    r = torch.rand(yr.shape, generator=torch.Generator().manual_seed(9)) - 0.5
+    (yr * r).sum().backward()
+    (y * r.cuda()).sum().backward()
+    assert rel_err(x.grad.cpu(), xr.grad) < TOL
+    with pytest.raises(RuntimeError):
+        mce.vgg_4conv_1maxPool()                                  # no torchvision / checkpoint here: refuses, as the reference fails
