@@ -8,10 +8,15 @@
 // 64 cycles; 75 MB of tensors).  The generic kernel reaches ~53 % of the fp32 MFMA peak: its 256-thread workgroups
 // alternate staging and MFMA phases and re-stage the weights for every tile.  This kernel keeps the matrix pipe fed:
 //   * a workgroup owns ONE output-channel half (32 couts): its share of the weights (32 x 576 floats = 74 KB) stays in
-//     LDS for the whole launch ([chunk][tap][ci 32][co 32 + 1 pad]: conflict-free transposed fill, conflict-free reads);
+//     LDS for the whole launch ([chunk][tap][co 32][ci 32 + 4 pad]);
 //   * it walks 8 x 16 pixel tiles; four consumer waves (one 32-pixel x 32-cout accumulator tile each, 288 MFMAs per tile)
-//     and four producer waves that stage the next 32-channel half of a halo tile ([pixel][33 floats], the generic
-//     kernel's conflict-free A layout) into the other LDS buffer behind the MFMAs: one barrier per (tile, channel half);
+//     and four producer waves that stage the next 32-channel half of a halo tile ([pixel][32 + 4 floats]) into the other
+//     LDS buffer behind the MFMAs: one barrier per (tile, channel half);
+//   * an fp32 MFMA takes ONE float per lane and operand, and a wave's other instructions do not overlap its own MFMAs (the
+//     32x32x2 fp32 form occupies the wave's issue for its 64 cycles: measured 78 cycles per MFMA with two ds_read_b32 each).
+//     The K order of the 16 MFMAs of a 32-channel slice is therefore chosen so that a lane's operands are CONTIGUOUS:
+//     lane half kk multiplies channels 16 kk + s at step s, so its 16 A values (and its 16 B values) are four
+//     ds_read_b128 instead of sixteen ds_read_b32 -- a quarter of the LDS instructions per MFMA;
 //   * 1152 pixel tiles x 2 cout halves = exactly 9 units per CU at the benchmark size (no partial round);
 //   * role-specific loops with matching barrier counts (see conv_trunk.hip).
 // The two workgroups of a cout pair walk the same pixel tiles and share one statistics row: each writes its 32 channels.
@@ -27,10 +32,12 @@ typedef unsigned cf_u32x4 __attribute__((ext_vector_type(4)));
 #define CF_IH (CF_TH + 2)
 #define CF_IW (CF_TW + 2)
 #define CF_NPIX (CF_IH * CF_IW)            // 180 halo pixels
-#define CF_PSF 33                           // floats per halo pixel in LDS (32 channels + 1: odd stride)
-#define CF_HALO_BYTES (CF_NPIX * CF_PSF * 4)   // 23760
-#define CF_WROW 33                          // floats per (tap, ci) weight row in LDS (32 couts + 1)
-#define CF_WCHUNK_BYTES (9 * 32 * CF_WROW * 4) // 38016
+#define CF_PSF 36                           // floats per halo pixel in LDS: 32 channels + 4 -- rows stay 16-byte aligned (the operand
+                                            // fetch is ds_read_b128) and 144-byte rows put 16 consecutive pixels on 16 different
+                                            // 16-byte bank slots (9 p mod 16): conflict-free
+#define CF_HALO_BYTES (CF_NPIX * CF_PSF * 4)   // 25920
+#define CF_WROW 36                          // floats per (tap, cout) weight row in LDS: its 32 input channels + 4 (as CF_PSF)
+#define CF_WCHUNK_BYTES (9 * 32 * CF_WROW * 4) // 41472
 #define CF_ITEMS ((CF_NPIX * 8 + 255) / 256)   // 16-byte items (4 channels of a 32-channel half) per producer thread: 6
 #define CF_THREADS 512
 #define CF_KROWP 100                        // packed fp32 weights: [chunk][r][cout 64][krow = s * 33 + ci], rows of 100
@@ -130,7 +137,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             const int ci = e & 31, s = (e >> 5) % 3, t2 = (e >> 5) / 3;
             const int co = t2 & 31, qr = t2 >> 5;
             const int q = qr / 3, r = qr - 3 * q;
-            wl[((q * 9 + r * 3 + s) * 32 + ci) * CF_WROW + co] = wv[it];
+            wl[((q * 9 + r * 3 + s) * 32 + co) * CF_WROW + ci] = wv[it];
         }
     };
 
@@ -207,8 +214,8 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
                     return qa[c] * g + qb[c] * bx + qd[c];
                 };
                 const f32x4 osum = {value(0), value(1), value(2), value(3)};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) img[k * 32 * CF_PSF + c] = ok ? osum[c] : 0.f;   // the halo is zero AFTER the transform
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(img + k * 32 * CF_PSF) = ok ? osum : zero4;        // the halo is zero AFTER the transform
                 // skip-sum prologue: the tile's own 8 x 16 pixels (no halo flag) store the materialised sum, once per pixel
                 // and channel half -- by the workgroup of cout half 0 (its partner stages the same tiles)
                 if (SUM && hc == 0 && ((flags >> (4 * k)) & 15u) == 0u)
@@ -255,11 +262,12 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
         }
     } else {
         // ---- consumers: wave w = tile rows 2 w, 2 w + 1 (32 pixels) x this workgroup's 32 couts -------------------------------
-        // operand lane roles (sisr_dev.h): A = x[pixel l31][ci = 2 s + kk], B = W[ci = 2 s + kk][co = l31];
+        // operand lane roles (sisr_dev.h; K order chosen here): A = x[pixel l31][ci = 16 kk + s], B = W[ci = 16 kk + s][co = l31];
         // accumulator register i of a lane = pixel mfma_row(i, lane) of the sub-tile, cout l31
         const int co = 32 * hc + l31;
-        const int abase = (((2 * wave + (l31 >> 4)) * CF_IW + (l31 & 15)) * CF_PSF + kk) * 4;
-        const int bbase = (kk * CF_WROW + l31) * 4;
+        // step s of a 32-channel slice: A = x[pixel l31][ci = 16 kk + s], B = W[ci = 16 kk + s][co = l31]
+        const int abase = (((2 * wave + (l31 >> 4)) * CF_IW + (l31 & 15)) * CF_PSF + 16 * kk) * 4;
+        const int bbase = (l31 * CF_WROW + 16 * kk) * 4;
         const float bv = a.bias != nullptr ? a.bias[co] : 0.f;
         float st_shift = 0.f, st_s1 = 0.f, st_s2 = 0.f;     // running statistics of this lane's values, shifted sums
         int st_n = 0;
@@ -310,24 +318,24 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             // MFMAs of half-tap u, so a whole half-tap (512 cycles) of reads is always in flight (left alone the compiler
             // requests a pair of operands right before the MFMAs that need them; groups of 8 reads keep the wait expressible in
             // the 4-bit lgkmcnt)
-            float af[18][8], bf[18][8];
+            f32x4 af[18][2], bf[18][2];                     // half-tap u: steps s0 .. s0 + 7 = two 16-byte reads per operand
             auto fetch = [&](int u) {
                 const int t = u >> 1, s0 = 8 * (u & 1);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    af[u][s] = *reinterpret_cast<const float*>(ab + (((t / 3) * CF_IW + (t % 3)) * CF_PSF + 2 * (s0 + s)) * 4);
-                    bf[u][s] = *reinterpret_cast<const float*>(bb + ((t * 32 + 2 * (s0 + s)) * CF_WROW) * 4);
+                for (int v = 0; v < 2; ++v) {
+                    af[u][v] = *reinterpret_cast<const f32x4*>(ab + (((t / 3) * CF_IW + (t % 3)) * CF_PSF + s0 + 4 * v) * 4);
+                    bf[u][v] = *reinterpret_cast<const f32x4*>(bb + ((t * 32) * CF_WROW + s0 + 4 * v) * 4);
                 }
             };
             fetch(0);
             fetch(1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
             for (int u = 0; u < 18; ++u) {
                 if (u + 2 < 18) fetch(u + 2);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u][s], bf[u][s], acc, 0, 0, 0);
-                if (u + 2 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u][s >> 2][s & 3], bf[u][s >> 2][s & 3], acc, 0, 0, 0);
+                if (u + 2 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
             CFT(6 + 6 * j);

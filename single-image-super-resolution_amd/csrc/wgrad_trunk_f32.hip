@@ -34,6 +34,23 @@
 #define WF_PS 33                            // generic fp32 plan: krow = s * PS + ci
 #define WF_KROWP 100
 
+// barrier-wait accounting, developer build only (-DSISR_BARRIER_ACCT; tools/barrier_acct.py): see conv_trunk.hip
+#ifdef SISR_BARRIER_ACCT
+__device__ unsigned long long sisr_wfacct_buf[512 * 8];
+extern "C" int sisr_wfacct_read(void* dst, int n_u64) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sisr_wfacct_buf), (size_t)n_u64 * 8, 0, hipMemcpyDeviceToHost);
+}
+#define WFA_DECL unsigned long long ba_wait = 0, ba_t0 = clock64()
+#define WFA_SYNC() do { const unsigned long long b0_ = clock64(); __syncthreads(); ba_wait += clock64() - b0_; } while (0)
+#define WFA_STORE(slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) { sisr_wfacct_buf[blockIdx.x * 8 + (slot)] = clock64() - ba_t0; sisr_wfacct_buf[blockIdx.x * 8 + (slot) + 1] = ba_wait; } } while (0)
+#define WFA_MARK(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512) sisr_wfacct_buf[blockIdx.x * 8 + (slot)] = clock64(); } while (0)
+#else
+#define WFA_DECL
+#define WFA_SYNC() __syncthreads()
+#define WFA_STORE(slot)
+#define WFA_MARK(slot)
+#endif
+
 struct WTrunkF32Args {
     const float *x1, *g1, *g2;
     const float *pa, *pd;                   // x prologue (AFFINE_ACT)
@@ -70,7 +87,7 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         return (unsigned)(((n * a.H + ty * WF_TH) * a.W + tx * WF_TW) * 256);
     };
     float* sl = a.slab + (int64_t)blockIdx.x * a.slab_stride;
-
+    // (accounting marks of thread 0, a consumer: 4 = role state ready, 5 = first barrier passed, 6 = tile loop done, 7 = end)
     if (!consumer) {
         // ---- producers: both operands of tile T + 1 while the consumers multiply tile T ------------------------------------
         // item k of thread pt: pixel pt / 16 + 16 k (of the halo for x, of the tile for the gradient), channels 4 (pt % 16) ..
@@ -154,12 +171,14 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         int T = blockIdx.x;
         if (T < a.total) produce(T, 0);
         __syncthreads();
+        WFA_DECL;
         int cur = 0;
         for (; T < a.total; T += gridDim.x, cur ^= 1) {
             const int Tn = T + gridDim.x;
             if (Tn < a.total) produce(Tn, cur ^ 1);
-            __syncthreads();      // the next tile's images are complete; the consumers have finished reading this one
+            WFA_SYNC();           // the next tile's images are complete; the consumers have finished reading this one
         }
+        if (wave == 4) WFA_STORE(2);
         if (a.bias_slab != nullptr) *reinterpret_cast<f32x4*>(lds + pt * 16) = bsum;      // the images are free by now
     } else {
         // ---- consumers: (32 output channels) x (9 taps x 32 input channels) in accumulators, across all tiles ---------------
@@ -170,7 +189,10 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
         // operand lane roles (sisr_dev.h): A = x[pixel 2 s + kk][ci = l31], B = dy[pixel 2 s + kk][co = l31]
         const int xoff = kk * WF_PB + (32 * gq + l31) * 4, doff = WF_XBYTES + kk * WF_PB + (32 * h + l31) * 4;
+        WFA_MARK(4);
         __syncthreads();
+        WFA_MARK(5);
+        WFA_DECL;
         int cur = 0;
         for (int T = blockIdx.x; T < a.total; T += gridDim.x, cur ^= 1) {
             const unsigned char* xb = lds + cur * (WF_XBYTES + WF_DBYTES) + xoff;
@@ -195,8 +217,10 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
                     }
                 }
             }
-            __syncthreads();
+            WFA_SYNC();
         }
+        if (wave == 0) WFA_STORE(0);
+        WFA_MARK(6);
         // one slab per workgroup: [chunk gq][filter row ky][kx * 33 + ci][64 co]
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -214,6 +238,7 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
             a.bias_slab[(int64_t)blockIdx.x * a.slab_stride + tid] = s;
         }
     }
+    WFA_MARK(7);
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------

@@ -8,6 +8,20 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import bench
 dev = torch.device('cuda', 0)
+if os.environ.get('ROLE') == 'wgrad_f32':
+    r = bench.kernel_rooflines(dev, 'fp32', iters=20, only=('wgrad',))[0]
+    print('fp32 wgrad + slab reduce launch %.2f us (HIP events)' % (r['launch_ms'] * 1e3))
+    torch.cuda.synchronize()
+    L = C.CDLL(os.environ['SISR_LIB'])
+    buf = np.zeros(512 * 8, dtype=np.uint64)
+    assert L.sisr_wfacct_read(buf.ctypes.data_as(C.c_void_p), C.c_int(buf.size)) == 0
+    b = buf.reshape(512, 8).astype(np.float64)
+    b = b[b[:, 0] > 0]
+    md = lambda v: float(np.median(v))
+    print('%d workgroups; cycles (median): consumer tile loop %.0f (at barriers %.0f); producer loop %.0f (at barriers %.0f)' % (
+        len(b), md(b[:, 0]), md(b[:, 1]), md(b[:, 2]), md(b[:, 3])))
+    print('  prologue barrier wait %.0f; slab store + bias tail after the loop %.0f' % (md(b[:, 5] - b[:, 4]), md(b[:, 7] - b[:, 6])))
+    sys.exit(0)
 r = bench.kernel_rooflines(dev, 'bf16', iters=20, only=('fwd',))[0]
 print('fwd launch %.2f us (HIP events)' % (r['launch_ms'] * 1e3))
 torch.cuda.synchronize()
