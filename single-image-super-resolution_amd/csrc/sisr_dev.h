@@ -376,7 +376,11 @@ struct BnFinArgs {
     int rows;
     float momentum, eps;
 };
+// NT = threads of the workgroup (512: two waves per SIMD; 256: the one-wave-per-SIMD kernels): NT / 16 row splits, summed in
+// 4 groups through LDS (scratch: NT / 16 x 64 x 3 doubles)
+template <int NT = 512>
 __device__ __forceinline__ void bn_finalize_in_kernel(const BnFinArgs& f, double* scratch, float* kfin, bool writer) {
+    constexpr int NSPLIT = NT / 16, PER_GROUP = NSPLIT / 4;
     // thread = (4 consecutive channels c4, one of 32 row splits): 16-byte loads, ~8 rows per thread at 231 rows -- two
     // memory round trips instead of the eight of a (channel, 8 splits) mapping; the 32 partial sums of a channel are
     // then added in two fixed-order stages (4 groups of 8 through LDS)
@@ -387,7 +391,7 @@ __device__ __forceinline__ void bn_finalize_in_kernel(const BnFinArgs& f, double
 #define BNFIN_UNROLL 4
 #endif
 #pragma unroll BNFIN_UNROLL
-    for (int t = split32; t < f.rows; t += 32) {
+    for (int t = split32; t < f.rows; t += NSPLIT) {
         const double nb = (double)f.cnt[t];
         const f32x4 mb = *reinterpret_cast<const f32x4*>(f.stat + (int64_t)t * 128 + 4 * c4);
         const f32x4 qb = *reinterpret_cast<const f32x4*>(f.stat + (int64_t)t * 128 + 64 + 4 * c4);
@@ -406,13 +410,13 @@ __device__ __forceinline__ void bn_finalize_in_kernel(const BnFinArgs& f, double
         w[0] = N4; w[1] = S4[j]; w[2] = Q4[j];
     }
     __syncthreads();
-    const int c = threadIdx.x & 63, split = threadIdx.x >> 6;          // split = group of 8 row splits (0 .. 7; 4 .. 7 idle)
+    const int c = threadIdx.x & 63, split = threadIdx.x >> 6;          // split = group of PER_GROUP row splits (groups 4 .. idle)
     const double K = (double)f.stat[c];
     double N = 0.0, S = 0.0, Q = 0.0;
     if (split < 4) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const double* r = scratch + ((8 * split + j) * 64 + c) * 3;
+        for (int j = 0; j < PER_GROUP; ++j) {
+            const double* r = scratch + ((PER_GROUP * split + j) * 64 + c) * 3;
             N += r[0]; S += r[1]; Q += r[2];
         }
     }
