@@ -122,34 +122,42 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         const int grel0 = ((m0 >> 4) * a.W + (m0 & 15)) * 256 + quad * 16;   // tile pixel m0 + 16 k: one row further down per item
         const int xlds0 = m0 * WF_PB + quad * 16, glds0 = WF_XBYTES + m0 * WF_PB + quad * 16;
 
-        auto produce = [&](int T, int b) {
+        // two staging register sets: the loads of tile T + 2 are in flight while tile T + 1 is transformed and written to LDS
+        // (a tile lasts ~8 us of MFMAs; loading synchronously inside that window left the consumers waiting at 12 % of their
+        // barriers' time for a late tile: tools/barrier_acct.py).  issue() is always executed -- past the last tile every offset
+        // is out of range: an instruction, no traffic -- so that the loop has no control flow around loads.
+        struct Stage { f32x4 sx[WF_XITEMS], s1[4], s2[4]; unsigned okm; };
+        Stage stA, stB;
+        auto issue = [&](int T, Stage& st) {
             const __amdgpu_buffer_rsrc_t rx = wf_rsrc(a.x1, tbytes), r1 = wf_rsrc(a.g1, tbytes), r2 = wf_rsrc(a.g2, tbytes);
             int ty, tx;
             const unsigned origin = tile_origin(T, ty, tx);
+            const bool live = T < a.total;
             // every tile has an edge pattern; 15 marks "always outside" items (beyond the halo), which any non-zero mask hits
             const unsigned e = (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u);
-            f32x4 sx[WF_XITEMS], s1[4], s2[4];
-            unsigned okm = 0;
+            st.okm = 0;
 #pragma unroll
             for (int k = 0; k < WF_XITEMS; ++k) {
                 const unsigned f = (xflags >> (4 * k)) & 15u;
-                const bool ok = f != 15u && (f & e) == 0u;
-                okm |= ok ? (1u << k) : 0u;
-                sx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? origin + (unsigned)xrel[k] : 0x80000000u, 0, 0));
+                const bool ok = live && f != 15u && (f & e) == 0u;
+                st.okm |= ok ? (1u << k) : 0u;
+                st.sx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? origin + (unsigned)xrel[k] : 0x80000000u, 0, 0));
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const unsigned voff = origin + (unsigned)(grel0 + k * a.W * 256);
-                s1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0));
-                s2[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0));
+                const unsigned voff = live ? origin + (unsigned)(grel0 + k * a.W * 256) : 0x80000000u;
+                st.s1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0));
+                st.s2[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0));
             }
+        };
+        auto commit = [&](const Stage& st, int b) {
             unsigned char* img = lds + b * (WF_XBYTES + WF_DBYTES);
             // x: lrelu(a x + d) (a = 1, d = 0, slope = 1 degenerate to ACT / NONE), zero outside the image
 #pragma unroll
             for (int k = 0; k < WF_XITEMS; ++k) {
                 f32x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (okm >> k) & 1u ? lrelu(ka[j] * sx[k][j] + kd[j], xslope) : 0.f;
+                for (int j = 0; j < 4; ++j) o[j] = (st.okm >> k) & 1u ? lrelu(ka[j] * st.sx[k][j] + kd[j], xslope) : 0.f;
                 if (k < WF_XITEMS - 1 || !last_beyond) *reinterpret_cast<f32x4*>(img + xlds0 + k * 16 * WF_PB) = o;
             }
             // gradient: BatchNorm backward (through the activation for BNACT_BWD); the bias gradient is summed on the way
@@ -158,8 +166,8 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float g = s1[k][j];
-                    const float bx = s2[k][j];
+                    float g = st.s1[k][j];
+                    const float bx = st.s2[k][j];
                     if (GPRO == SISR_PRO_BNACT_BWD) g = qs[j] * bx + qt[j] > 0.f ? g : gslope * g;
                     o[j] = qa[j] * g + qb[j] * bx + qd[j];
                 }
@@ -169,16 +177,26 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         };
 
         int T = blockIdx.x;
-        if (T < a.total) produce(T, 0);
+        issue(T, stA);
+        issue(T + gridDim.x, stB);
+        if (T < a.total) commit(stA, 0);
         __syncthreads();
         WFA_DECL;
+        // unrolled by two: each staging set has a fixed name in each half (stB holds tile T + grid in the first)
         int cur = 0;
-        for (; T < a.total; T += gridDim.x, cur ^= 1) {
-            const int Tn = T + gridDim.x;
-            if (Tn < a.total) produce(Tn, cur ^ 1);
+        while (T < a.total) {
+            issue(T + 2 * gridDim.x, stA);
+            if (T + (int)gridDim.x < a.total) commit(stB, cur ^ 1);
             WFA_SYNC();           // the next tile's images are complete; the consumers have finished reading this one
+            T += gridDim.x; cur ^= 1;
+            if (T >= a.total) break;
+            issue(T + 2 * gridDim.x, stB);
+            if (T + (int)gridDim.x < a.total) commit(stA, cur ^ 1);
+            WFA_SYNC();
+            T += gridDim.x; cur ^= 1;
         }
         if (wave == 4) WFA_STORE(2);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the prefetch loads past the last tile
         if (a.bias_slab != nullptr) *reinterpret_cast<f32x4*>(lds + pt * 16) = bsum;      // the images are free by now
     } else {
         // ---- consumers: (32 output channels) x (9 taps x 32 input channels) in accumulators, across all tiles ---------------
