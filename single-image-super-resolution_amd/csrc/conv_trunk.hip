@@ -374,18 +374,24 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
             //           [32 couts][64 pixels] image (pixels 32 ms + 8 q + 4 kk .. + 3 of cout l31)
             //   4, 5    16-pixel block pb = 2 ms + (sl - 4) = tile row 4 g + pb: transposing reads, one 16-byte store
             auto epi = [&](int sl, const f32x16& acc, int ms, bool first, int n, int ty, int tx) {
+#ifdef SISR_ABLATE_EPI          // timing-only ablation (no output): the consumers' epilogue is skipped
+                if (a.N > 0) { asm volatile("" :: "v"(acc[0])); return; }
+#endif
                 if (sl < 4) {
                     const int q = sl;
+                    // (the accumulators start from zero -- a literal operand of the first MFMA -- and the bias joins here: an
+                    // accumulator set initialised to the bias keeps a 16-register copy of it alive for the whole launch)
                     if (STATS) {
                         if (first && q == 0) {                      // shift = mean of the first sub-tile's values of this lane
                             float sm = 0.f;
 #pragma unroll
                             for (int i = 0; i < 16; ++i) sm += acc[i];
-                            st_shift = sm * (1.f / 16.f);
+                            st_shift = sm * (1.f / 16.f) + bv;
                         }
+                        const float st_c = bv - st_shift;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float dv = acc[4 * q + j] - st_shift;
+                            const float dv = acc[4 * q + j] + st_c;
                             st_s1 += dv;
                             st_s2 += dv * dv;
                         }
@@ -393,7 +399,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
                     }
                     bf16x4 hv;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) hv[j] = (__bf16)acc[4 * q + j];
+                    for (int j = 0; j < 4; ++j) hv[j] = (__bf16)(acc[4 * q + j] + bv);
                     *reinterpret_cast<bf16x4*>(my_out + l31 * TK_YS + 32 * ms + 8 * q + 4 * kk) = hv;
                 } else {
                     const int pb = 2 * ms + (sl - 4);               // group = channel octet
@@ -414,7 +420,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
             // one phase: 36 MFMAs into `acc` over sub-tile `ms` of halo image `ib`; `under(c)` runs after MFMA c
             auto phase = [&](f32x16& acc, const unsigned char* ib, int ms, auto&& under) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = bv;           // the bias: every register of a lane is its channel
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
                 bf16x8 af[36];
                 const unsigned char* pa = ib + a_base[ms];
                 auto fetch = [&](int st) {
@@ -422,12 +428,24 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
                     af[st] = *reinterpret_cast<const bf16x8*>(pa + (t / 3) * TK_RP + (t % 3) * TK_PSB + j * 32);
                 };
 #pragma unroll
+#ifdef SISR_ABLATE_AREADS
+                for (int st = 0; st < TK_PFA; st += 2) fetch(st);
+#else
                 for (int st = 0; st < TK_PFA; ++st) fetch(st);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int st = 0; st < 36; ++st) {
+#ifdef SISR_ABLATE_AREADS      // timing-only ablation (wrong results): every second A fragment is not fetched but reused
+                    if (st + TK_PFA < 36 && ((st + TK_PFA) & 1) == 0) fetch(st + TK_PFA);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st & ~1], bw[st >> 2][st & 3], acc, 0, 0, 0);
+#elif defined(SISR_ABLATE_MFMA)  // timing-only ablation (wrong results): fragment reads without the matrix instructions
+                    if (st + TK_PFA < 36) fetch(st + TK_PFA);
+                    asm volatile("" :: "v"(af[st]), "v"(bw[st >> 2][st & 3]));
+#else
                     if (st + TK_PFA < 36) fetch(st + TK_PFA);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st], bw[st >> 2][st & 3], acc, 0, 0, 0);
+#endif
                     under(st);
                     __builtin_amdgcn_sched_barrier(0);              // the source order IS the software pipeline
                 }
@@ -466,6 +484,27 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
             if (it > 0) {                                           // the last tile's second sub-tile
 #pragma unroll
                 for (int sl = 0; sl < 6; ++sl) epi(sl, acc1, 1, false, pn, pty, ptx);
+            }
+#elif TK_DEFER == 2
+            // ONE accumulator set: each sub-tile's epilogue follows its own 36 MFMAs.  The 16 registers this frees go to the
+            // A-fragment prefetch (8 instead of 4 in flight): the consumers are bound by LDS LATENCY at a prefetch of 4 --
+            // ablations (tools/barrier_acct.py builds): without any MFMA the 72 fragment reads of a tile still take ~2,000
+            // cycles (4 in flight x ~110 cycles each), halving the reads at the same depth changes nothing
+            for (int T = t_first; T < a.total; T += t_step, cur ^= 1, ++it) {
+                TT(4 + 6 * it);
+                tile_coords(T, n, ty, tx);
+                const unsigned char* ib = lds + cur * (TK_HALO_BYTES);
+                const bool first = it == 0;
+                phase(acc0, ib, 0, [&](int) {});
+#pragma unroll
+                for (int sl = 0; sl < 6; ++sl) epi(sl, acc0, 0, first, n, ty, tx);
+                TT(6 + 6 * it);
+                phase(acc0, ib, 1, [&](int) {});
+#pragma unroll
+                for (int sl = 0; sl < 6; ++sl) epi(sl, acc0, 1, false, n, ty, tx);
+                TT(8 + 6 * it);
+                BA_SYNC();
+                TT(9 + 6 * it);
             }
 #else
             // sub-tile 0's epilogue under sub-tile 1's MFMAs; sub-tile 1's own epilogue follows its phase (no accumulator
