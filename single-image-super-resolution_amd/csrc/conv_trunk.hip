@@ -185,7 +185,8 @@ __device__ __forceinline__ u32x4 trunk_apply8(u32x4 a, u32x4 b, const f32x8& ka,
 #define TK_PF 3                           // A-fragment prefetch distance of the data-gradient consumers' MFMA loop, in steps of 2 MFMAs
 #endif
 #ifndef TK_DEFER
-#define TK_DEFER 0                        // 1: also defer sub-tile 1's epilogue under the next tile's first phase (A/B variant)
+#define TK_DEFER 0                        // A/B variants: 1 = also defer sub-tile 1's epilogue under the next tile's first phase; 2 = one
+                                          // accumulator set, each sub-tile's epilogue right behind its own phase
 #endif
 #ifndef TK_PFA
 #define TK_PFA 4                          // ... of the forward consumers' phases, in MFMAs (5 and more spill: 256 VGPRs are in use)
@@ -453,7 +454,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
             int cur = 0, it = 0;
             int n, ty, tx;
             BA_DECL;
-#if TK_DEFER
+#if TK_DEFER == 1
             // sub-tile 1's epilogue deferred under the NEXT tile's first phase (its accumulators live across the barrier)
             int T = t_first, pn = 0, pty = 0, ptx = 0;
             if (T < a.total) {
