@@ -112,7 +112,10 @@ typedef struct SisrConvDesc {
      * activations and gradients as bf16 in HBM; all arithmetic, accumulation and statistics stay fp32).
      * x_bf16: x1 and x2;  y_bf16: y (NHWC / NHWC_SHUFFLE2 only);  res_bf16: res;  bnbx_bf16: bnb_x. */
     int32_t x_bf16, y_bf16, res_bf16, bnbx_bf16;
-    int32_t fin_rows; float fin_momentum, fin_eps; int32_t fin_pad_;
+    int32_t fin_rows; float fin_momentum, fin_eps;
+    /* fp32 tensors, trunk geometry only: 1 = the contraction runs on the bf16 matrix instruction over (hi, lo) bf16 pairs of every
+     * fp32 operand (hi*hi + hi*lo + lo*hi, fp32 accumulate; operands good to 2^-17 relative); 0 = exact fp32 matrix instruction */
+    int32_t mfma_split;
     SisrConvPlan plan;
 } SisrConvDesc;
 

@@ -41,7 +41,7 @@ class ConvDesc(C.Structure):
                 [('y_mode', _i32), ('epi_act', _i32), ('bnb_act', _i32), ('bnb_slope', _f32)] +
                 [(n, _i32) for n in ('y_sy', 'y_oy', 'y_sx', 'y_ox', 'y_H', 'y_W')] +
                 [(n, _i32) for n in ('x_bf16', 'y_bf16', 'res_bf16', 'bnbx_bf16')] +
-                [('fin_rows', _i32), ('fin_momentum', _f32), ('fin_eps', _f32), ('fin_pad_', _i32)] +
+                [('fin_rows', _i32), ('fin_momentum', _f32), ('fin_eps', _f32), ('mfma_split', _i32)] +
                 [('plan', ConvPlan)])
 
 

@@ -188,6 +188,12 @@ __device__ __forceinline__ u32x4 trunk_apply8(u32x4 a, u32x4 b, const f32x8& ka,
 #define TK_DEFER 0                        // A/B variants: 1 = also defer sub-tile 1's epilogue under the next tile's first phase; 2 = one
                                           // accumulator set, each sub-tile's epilogue right behind its own phase
 #endif
+#ifndef TK_EARLY
+#define TK_EARLY 0
+#endif
+#ifndef SISR_ABLATE_WLOAD
+#define SISR_ABLATE_WLOAD 0
+#endif
 #ifndef TK_PFA
 #define TK_PFA 4                          // ... of the forward consumers' phases, in MFMAs (5 and more spill: 256 VGPRs are in use)
 #endif
@@ -237,7 +243,6 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     // buffers are free yet: 48 KB of scratch, the constants behind the reduction scratch)
     float* kfin = red + 4 * 32 * 3;
     const bool fin = (PRO == SISR_PRO_AFFINE_ACT || PRO == SISR_PRO_RES_AFFINE) && a.fin.stat != nullptr;
-    if (fin) bn_finalize_in_kernel(a.fin, reinterpret_cast<double*>(lds), kfin, blockIdx.x == 0);
     // (role state is set up INSIDE the role branches below: set up ahead of the split, every register of both roles
     // meets in one merge block and the allocator spills weights at load time)
     auto init_consumer = [&]() {
@@ -247,8 +252,16 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+#if SISR_ABLATE_WLOAD == 1       // timing-only (wrong values): what fully coalesced weight loads would cost
+                const unsigned off = (unsigned)(((((cg * 2 + h) * 9 + t) * 4 + j) * 64 + lane) * 16);
+#else
                 const unsigned off = (unsigned)((((j >> 1) * a.cout_pad + co) * 9 + t) * 32 + (j & 1) * 16 + 8 * kk) * 2u;
+#endif
+#if SISR_ABLATE_WLOAD == 2       // timing-only: no weight loads at all
+                bw[t][j] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)off, (unsigned)lane, 1u, 2u});
+#else
                 bw[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
+#endif
             }
         // A operand of sub-tile ms: lane (l31, kk) = pixel (tile row 4g + 2ms + (l31 >> 4), column l31 & 15), channels 8kk..
 #pragma unroll
@@ -313,16 +326,36 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     __bf16* my_out = out_img + (wave & 3) * (32 * TK_YS);
     const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
 
+#if !TK_EARLY
+    if (fin) bn_finalize_in_kernel(a.fin, reinterpret_cast<double*>(lds), kfin, blockIdx.x == 0);
+#endif
     // Two role-specific tile loops with matching barrier counts (a barrier only counts arriving waves).  Written as ONE
     // loop with a role branch inside, the register allocator carries the consumers' 144 weight registers through the
     // producers' code (and the producers' staging registers through the consumers').
     if (!consumer) {
         // ---- producers: tile T + 1 into the other buffer while the consumers work on tile T ------------------------------
-        init_producer();
         int T = t_first;
-        init_constants();
+#if TK_EARLY
+        // every wave's first memory requests go out BEFORE the BatchNorm finalisation and the per-channel constants: the
+        // producers' first two tiles (and the consumers' weights) are raw loads that depend on nothing computed here.  (The
+        // finalisation is instantiated once per role: as common code between two role branches it would keep both roles'
+        // registers live at once.)
+        halo_map_init(hm, ptid, a.W);
         issue(T, stA);
         issue(T + t_step, stB);
+        if (fin) bn_finalize_in_kernel(a.fin, reinterpret_cast<double*>(lds), kfin, blockIdx.x == 0);
+        slope = a.slope_p ? a.slope_p[0] : a.slope;
+        easy_slope = slope >= 0.f && slope <= 1.f;
+        init_constants();
+        TTP(0);
+#else
+        init_producer();
+        init_constants();
+        TTP(0);
+        issue(T, stA);
+        issue(T + t_step, stB);
+#endif
+        TTP(1);
         if (T < a.total) commit(lds, stA);
         TTP(2);
         __syncthreads();
@@ -356,7 +389,14 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
         if (wave == 4) BA_STORE(2);
     } else {
         init_consumer();
+#if TK_EARLY
+        if (fin) bn_finalize_in_kernel(a.fin, reinterpret_cast<double*>(lds), kfin, blockIdx.x == 0);
+#endif
         TT(2);
+#ifdef SISR_CONV_TRACE
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // (trace build: when the weights have landed)
+        TT(58);
+#endif
         __syncthreads();
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the weights (long here: the barrier took microseconds)
         // ---- consumers.  A tile is two sub-tiles of 32 pixels (tile rows 4g + 2ms, 4g + 2ms + 1) x this wave's 32 couts,

@@ -21,12 +21,19 @@
 //   * role-specific loops with matching barrier counts (see conv_trunk.hip).
 // The two workgroups of a cout pair walk the same pixel tiles and share one statistics row: each writes its 32 channels.
 #include "sisr_dev.h"
+#include "sisr_bf16_stage.h"
 
 typedef unsigned cf_u32x4 __attribute__((ext_vector_type(4)));
 
 #include <algorithm>
 #include <cstdlib>
 
+#ifndef CF_CHAINS
+#define CF_CHAINS 1
+#endif
+#ifndef CF_PRODPRIO
+#define CF_PRODPRIO 0
+#endif
 #define CF_TH 8
 #define CF_TW 16
 #define CF_IH (CF_TH + 2)
@@ -88,7 +95,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t cf_rsrc(const void* p, unsigne
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
-template <int PRO>
+// two fp32 values -> their bf16 heads (round to nearest even) and the bf16 of what the heads leave: x = hi + lo up to 2^-17 |x|
+__device__ __forceinline__ void cf_split2(float v0, float v1, unsigned& hw, unsigned& lw) {
+    const f32x2 v = {v0, v1};
+    hw = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {v0 - __uint_as_float(hw << 16), v1 - __uint_as_float(hw & 0xFFFF0000u)};
+    lw = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+
+// SPLIT: the same kernel with every fp32 operand held in LDS as a (hi, lo) pair of bf16 -- 32 channels of a pixel / of a weight
+// row are [32 hi][32 lo], the 128 bytes the 32 floats took -- and the contraction done by the bf16 matrix instruction
+// (v_mfma_f32_32x32x16_bf16) as hi*hi + hi*lo + lo*hi into the fp32 accumulators: 54 MFMAs of 32 cycles per stage instead of
+// 144 of 64, products exact, operands good to 2^-17 relative (the lo*lo term, 2^-18, is dropped).  Tensors in HBM, prologue
+// arithmetic, accumulation, statistics and epilogue are the fp32 kernel's, unchanged.
+template <int PRO, bool SPLIT>
 __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTrunkF32Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     // [weights: 2 chunks][halo buffer 0][halo buffer 1][reduction scratch]
@@ -137,7 +157,16 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             const int ci = e & 31, s = (e >> 5) % 3, t2 = (e >> 5) / 3;
             const int co = t2 & 31, qr = t2 >> 5;
             const int q = qr / 3, r = qr - 3 * q;
-            wl[((q * 9 + r * 3 + s) * 32 + co) * CF_WROW + ci] = wv[it];
+            if constexpr (SPLIT) {
+                // lanes 2m / 2m + 1 hold input channels 2m / 2m + 1 of one row: the even lane writes the hi pair, the odd one the lo pair
+                const float vo = __shfl_xor(wv[it], 1);
+                const bool odd = ci & 1;
+                unsigned hw, lw;
+                cf_split2(odd ? vo : wv[it], odd ? wv[it] : vo, hw, lw);
+                reinterpret_cast<unsigned*>(wl)[((q * 9 + r * 3 + s) * 32 + co) * CF_WROW + (odd ? 16 : 0) + (ci >> 1)] = odd ? lw : hw;
+            } else {
+                wl[((q * 9 + r * 3 + s) * 32 + co) * CF_WROW + ci] = wv[it];
+            }
         }
     };
 
@@ -145,6 +174,9 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
     const int n_stages = 2 * n_mine;                                                               // (tile, channel half)
 
     if (!consumer) {
+#if CF_PRODPRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         // ---- producers: stage j + 1 = (tile (j + 1) / 2, channel half (j + 1) % 2) while the consumers multiply stage j -----
         // item k of thread pt: halo pixel pt / 8 + 32 k, channels 4 (pt % 8) .. + 3 of the 32-channel half
         const int pt = tid & 255, quad = tid & 7, m0 = pt >> 3;
@@ -163,7 +195,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             flags |= f << (4 * k);
         }
         const bool last_beyond = m0 + 32 * (CF_ITEMS - 1) >= CF_NPIX;
-        const int ldso = (m0 * CF_PSF + quad * 4) * 4;
+        const int ldso = SPLIT ? m0 * CF_PSF * 4 + quad * 8 : (m0 * CF_PSF + quad * 4) * 4;
 
         // two staging register sets: the loads of stage j + 2 fly while stage j + 1 is transformed and written to LDS (a
         // stage lasts ~4 us of MFMAs; a cold load round trip under a chip-wide load burst is not much shorter).  issue() is
@@ -215,6 +247,16 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
                 };
                 const f32x4 osum = {value(0), value(1), value(2), value(3)};
                 const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (SPLIT) {
+                    typedef unsigned cf_u32x2 __attribute__((ext_vector_type(2)));
+                    unsigned h0, l0, h1, l1;
+                    cf_split2(osum[0], osum[1], h0, l0);
+                    cf_split2(osum[2], osum[3], h1, l1);
+                    const cf_u32x2 hw = {h0, h1}, lw = {l0, l1};
+                    const cf_u32x2 z2 = {0u, 0u};
+                    *reinterpret_cast<cf_u32x2*>(img + k * 32 * CF_PSF) = ok ? hw : z2;
+                    *reinterpret_cast<cf_u32x2*>(img + k * 32 * CF_PSF + 16) = ok ? lw : z2;
+                } else
                 *reinterpret_cast<f32x4*>(img + k * 32 * CF_PSF) = ok ? osum : zero4;        // the halo is zero AFTER the transform
                 // skip-sum prologue: the tile's own 8 x 16 pixels (no halo flag) store the materialised sum, once per pixel
                 // and channel half -- by the workgroup of cout half 0 (its partner stages the same tiles)
@@ -266,13 +308,19 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
         // accumulator register i of a lane = pixel mfma_row(i, lane) of the sub-tile, cout l31
         const int co = 32 * hc + l31;
         // step s of a 32-channel slice: A = x[pixel l31][ci = 16 kk + s], B = W[ci = 16 kk + s][co = l31]
-        const int abase = (((2 * wave + (l31 >> 4)) * CF_IW + (l31 & 15)) * CF_PSF + 16 * kk) * 4;
-        const int bbase = (l31 * CF_WROW + 16 * kk) * 4;
+        // (SPLIT: step ks of a 32-channel slice is 16 channels, lane half kk multiplies channels 16 ks + 8 kk .. + 7: 16 bytes of the
+        // hi half of the row, and the same 16 bytes of the lo half 64 bytes on)
+        const int abase = SPLIT ? ((2 * wave + (l31 >> 4)) * CF_IW + (l31 & 15)) * CF_PSF * 4 + 16 * kk
+                                : (((2 * wave + (l31 >> 4)) * CF_IW + (l31 & 15)) * CF_PSF + 16 * kk) * 4;
+        const int bbase = SPLIT ? l31 * CF_WROW * 4 + 16 * kk : (l31 * CF_WROW + 16 * kk) * 4;
         const float bv = a.bias != nullptr ? a.bias[co] : 0.f;
         float st_shift = 0.f, st_s1 = 0.f, st_s2 = 0.f;     // running statistics of this lane's values, shifted sums
         int st_n = 0;
         const __amdgpu_buffer_rsrc_t ry = cf_rsrc(a.y, tbytes), rr = cf_rsrc(a.res != nullptr ? a.res : a.y, tbytes);
         f32x16 acc;
+#if CF_CHAINS == 2
+        f32x16 acc2;                                          // second accumulation chain (odd K steps), folded into acc before the epilogue
+#endif
         f32x16 rv, xv;                                        // residual / BatchNorm-input values of the tile (requested a stage early)
         const bool has_x = a.bnb_part != nullptr;
         const __amdgpu_buffer_rsrc_t rxb = cf_rsrc(has_x ? a.bnb_x : a.y, tbytes);
@@ -294,6 +342,10 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             if (q == 0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = bv;
+#if CF_CHAINS == 2
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+#endif
             } else {
                 // the skip gradient and the BatchNorm input of this tile, in accumulator layout: in flight behind the second
                 // half's MFMAs
@@ -318,6 +370,35 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             // MFMAs of half-tap u, so a whole half-tap (512 cycles) of reads is always in flight (left alone the compiler
             // requests a pair of operands right before the MFMAs that need them; groups of 8 reads keep the wait expressible in
             // the 4-bit lgkmcnt)
+            if constexpr (SPLIT) {
+                // tap t: two 16-channel steps x (hi, lo) per operand = eight 16-byte reads, six MFMAs; the reads run two taps ahead
+                bf16x8 ah[9][2], al[9][2], bh[9][2], bl[9][2];
+                auto fetch_s = [&](int t) {
+                    const unsigned char* pa = ab + ((t / 3) * CF_IW + (t % 3)) * CF_PSF * 4;
+                    const unsigned char* pb = bb + t * 32 * CF_WROW * 4;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        ah[t][ks] = *reinterpret_cast<const bf16x8*>(pa + 32 * ks);
+                        bh[t][ks] = *reinterpret_cast<const bf16x8*>(pb + 32 * ks);
+                        al[t][ks] = *reinterpret_cast<const bf16x8*>(pa + 64 + 32 * ks);
+                        bl[t][ks] = *reinterpret_cast<const bf16x8*>(pb + 64 + 32 * ks);
+                    }
+                };
+                fetch_s(0);
+                fetch_s(1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (t + 2 < 9) fetch_s(t + 2);
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t][ks], bh[t][ks], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t][ks], bl[t][ks], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t][ks], bh[t][ks], acc, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
             f32x4 af[18][2], bf[18][2];                     // half-tap u: steps s0 .. s0 + 7 = two 16-byte reads per operand
             auto fetch = [&](int u) {
                 const int t = u >> 1, s0 = 8 * (u & 1);
@@ -334,12 +415,28 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             for (int u = 0; u < 18; ++u) {
                 if (u + 2 < 18) fetch(u + 2);
 #pragma unroll
+#if CF_CHAINS == 2
+                for (int s = 0; s < 8; s += 2) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u][s >> 2][s & 3], bf[u][s >> 2][s & 3], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u][s >> 2][(s & 3) + 1], bf[u][s >> 2][(s & 3) + 1], acc2, 0, 0, 0);
+                }
+#else
                 for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u][s >> 2][s & 3], bf[u][s >> 2][s & 3], acc, 0, 0, 0);
+#endif
                 if (u + 2 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
+            }
             CFT(6 + 6 * j);
+#ifdef CF_ABLATE_EPI            // timing-only (no output): what the consumers' epilogue costs
+            if (q == 1 && a.N < 0) {
+#else
             if (q == 1) {
+#endif
+#if CF_CHAINS == 2
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+#endif
                 // ---- epilogue of the tile: skip gradient, statistics, stores (128 contiguous bytes per pixel and half wave) ---
                 if (a.res != nullptr) {
 #pragma unroll
@@ -387,6 +484,9 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
                                                           obase + (unsigned)(((p >> 4) * a.W + (p & 15)) * 256), 0, 0);
                 }
             }
+#ifdef CF_ABLATE_EPI
+            asm volatile("" :: "v"(acc));
+#endif
             CFT(8 + 6 * j);
             __syncthreads();
             CFT(9 + 6 * j);
@@ -503,14 +603,18 @@ extern "C" int sisr_conv2d_f32_bnb_parts(const SisrConvDesc* d) {
     return sisr_conv2d_trunk_f32_eligible(d) == 2 ? 2 * cf_streams(d) : 0;
 }
 
-template <int PRO>
-static int launch_cf(const CTrunkF32Args& a, hipStream_t st) {
+template <int PRO, bool SPLIT>
+static int launch_cf_t(const CTrunkF32Args& a, hipStream_t st) {
     constexpr int lds_bytes = 2 * CF_WCHUNK_BYTES + 2 * CF_HALO_BYTES + 4 * 32 * 3 * 4 + 128 * 4;
     static SisrLdsCap cap;
-    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&conv_trunk_f32_kernel<PRO>), lds_bytes)) return e;
-    hipLaunchKernelGGL((conv_trunk_f32_kernel<PRO>), dim3(2 * a.streams), dim3(CF_THREADS), lds_bytes, st, a);
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&conv_trunk_f32_kernel<PRO, SPLIT>), lds_bytes)) return e;
+    hipLaunchKernelGGL((conv_trunk_f32_kernel<PRO, SPLIT>), dim3(2 * a.streams), dim3(CF_THREADS), lds_bytes, st, a);
     SISR_CHECK_LAUNCH();
     return 0;
+}
+template <int PRO>
+static int launch_cf(const CTrunkF32Args& a, bool split, hipStream_t st) {
+    return split ? launch_cf_t<PRO, true>(a, st) : launch_cf_t<PRO, false>(a, st);
 }
 
 // called by sisr_conv2d_f32 for eligible descriptors
@@ -529,12 +633,12 @@ int sisr_conv2d_trunk_f32_launch(const SisrConvDesc* d, hipStream_t st) {
     a.bnb_slope_p = d->bnb_slope_p; a.bnb_slope = d->bnb_slope; a.bnb_act = d->bnb_act; a.bnb_part = d->bnb_part;
     a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);
     switch (d->pro_mode) {
-        case SISR_PRO_NONE: return launch_cf<SISR_PRO_NONE>(a, st);
-        case SISR_PRO_ACT: return launch_cf<SISR_PRO_ACT>(a, st);
-        case SISR_PRO_AFFINE_ACT: return launch_cf<SISR_PRO_AFFINE_ACT>(a, st);
-        case SISR_PRO_BNBWD: return launch_cf<SISR_PRO_BNBWD>(a, st);
-        case SISR_PRO_BNACT_BWD: return launch_cf<SISR_PRO_BNACT_BWD>(a, st);
-        case SISR_PRO_RES_AFFINE: return launch_cf<SISR_PRO_RES_AFFINE>(a, st);
+        case SISR_PRO_NONE: return launch_cf<SISR_PRO_NONE>(a, d->mfma_split != 0, st);
+        case SISR_PRO_ACT: return launch_cf<SISR_PRO_ACT>(a, d->mfma_split != 0, st);
+        case SISR_PRO_AFFINE_ACT: return launch_cf<SISR_PRO_AFFINE_ACT>(a, d->mfma_split != 0, st);
+        case SISR_PRO_BNBWD: return launch_cf<SISR_PRO_BNBWD>(a, d->mfma_split != 0, st);
+        case SISR_PRO_BNACT_BWD: return launch_cf<SISR_PRO_BNACT_BWD>(a, d->mfma_split != 0, st);
+        case SISR_PRO_RES_AFFINE: return launch_cf<SISR_PRO_RES_AFFINE>(a, d->mfma_split != 0, st);
     }
     return SISR_E_UNSUPPORTED;
 }

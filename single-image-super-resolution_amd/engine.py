@@ -20,9 +20,16 @@ PRECISION = os.environ.get('SISR_PRECISION', 'fp32')
 
 
 def set_precision(p):
+    """'fp32': fp32 tensors, exact fp32 matrix instructions.  'bf16x3': fp32 tensors and arithmetic as 'fp32', the trunk
+    contractions on the bf16 matrix instruction over (hi, lo) bf16 pairs of every fp32 operand (SisrConvDesc.mfma_split; operands
+    good to 2^-17 relative -- inside the 1e-3 parity bar by two orders of magnitude).  'bf16': bf16 tensors in HBM."""
     global PRECISION
-    assert p in ('fp32', 'bf16')
+    assert p in ('fp32', 'bf16x3', 'bf16')
     PRECISION = p
+
+
+def mfma_split():
+    return int(PRECISION == 'bf16x3')
 
 
 def storage_bf16():
@@ -406,6 +413,7 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
     f.wpk, f.bias, f.res, f.y = prep.wpk_fwd.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr()
     f.y_bf16, f.res_bf16 = _bf(out), _bf(res)
     f.epi_act = epi
+    f.mfma_split = mfma_split()
     fin = op.fin
     if fin is not None and not fin.done:
         # deferred BatchNorm finalisation: by this conv when it runs on a persistent trunk kernel, else stand-alone first
@@ -499,6 +507,7 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
     dy_op.fill(d)
     d.wpk, d.bias, d.res, d.y = prep.wpk_dgrad.data_ptr(), None, _ptr(res), out.data_ptr()
     d.y_bf16, d.res_bf16 = _bf(out), _bf(res)
+    d.mfma_split = mfma_split()
     part = None
     if bnb is not None:
         x, consts, slope = bnb

@@ -638,12 +638,18 @@ def test_trunk_kernel_weight_gradient_role_fp32(E, L, shape, xpro, gpro, monkeyp
     assert torch.equal(gw2, grads['1'][0]) and torch.equal(gb2, grads['1'][1])
 
 
+# the split build's contraction (SisrConvDesc.mfma_split): every fp32 operand as hi + lo bf16, good to 2^-17 = 7.6e-6 relative
+SPLIT_TOL = {'fp32': 1e-5, 'bf16x3': 4e-5}
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('pro', ['none', 'act', 'affine_act'])
 @pytest.mark.parametrize('shape', TRUNK_SHAPES)
-def test_trunk_kernel_fp32_forward_role(E, L, shape, pro, monkeypatch):
-    """conv_trunk_f32.hip (parity build: fp32 tensors, exact fp32 MFMA, weights of one cout half resident in LDS, producer /
-    consumer waves), forward role, against the generic fp32 kernel on the same operands and against F.conv2d in double:
-    output and the BatchNorm statistics merged from its per-stream partial rows"""
+def test_trunk_kernel_fp32_forward_role(E, L, shape, pro, precision, monkeypatch):
+    """conv_trunk_f32.hip (fp32 tensors, weights of one cout half resident in LDS, producer / consumer waves; 'fp32': exact fp32
+    MFMA, 'bf16x3': the bf16 MFMA over hi / lo pairs of the fp32 operands), forward role, against the generic fp32 kernel on
+    the same operands and against F.conv2d in double: output and the BatchNorm statistics merged from its per-stream partial rows"""
+    tol = SPLIT_TOL[precision]
     n, h, w = _walk(shape, monkeypatch)
     x = _rand((n, 64, h, w), 131) * 2.0
     wt = _rand((64, 64, 3, 3), 132, (1.0 / 576) ** 0.5 * 1.7)
@@ -656,38 +662,44 @@ def test_trunk_kernel_fp32_forward_role(E, L, shape, pro, monkeypatch):
     elif pro == 'affine_act':
         xin = F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.2)
     y_ref = F.conv2d(xin.double(), wt.double(), b.double(), padding=1)
-    E.set_precision('fp32')
-    ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 64, 3, 1, 1))
-    p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
-    assert not p.kinds[0]
-    xd = nhwc(x).cuda()
-    if pro == 'none':
-        op = E.Operand.plain(xd)
-    elif pro == 'act':
-        op = E.Operand.act(xd, slope.cuda())
-    else:
-        op = E.Operand.affine_act(xd, sc.cuda(), sh.cuda(), slope.cuda())
-    res = {}
-    for sw in ('1', '0'):
-        monkeypatch.setenv('SISR_TRUNK_F32CONV', sw)
-        y, sp, cp = E.conv_forward(p, op, bias=ref.bias, stats=True)
-        res[sw] = (y, sp, cp)
-    assert res['1'][1].shape[0] <= min(res['0'][1].shape[0], 128)            # one row per pair of workgroups, not per tile
-    assert maxrel(nchw(res['1'][0]), y_ref) < 1e-5
-    assert maxrel(res['1'][0], res['0'][0]) < 1e-5
-    t1, m1, v1 = _merged_stats(res['1'][1], res['1'][2])
-    t0, m0, v0 = _merged_stats(res['0'][1], res['0'][2])
-    assert t1 == t0 == n * h * w
-    assert maxrel(m1, m0) < 1e-5 and maxrel(v1, v0) < 1e-5
-    assert maxrel(m1, y_ref.mean(dim=(0, 2, 3))) < 1e-5 and maxrel(v1, y_ref.var(dim=(0, 2, 3), unbiased=False)) < 1e-5
-    monkeypatch.setenv('SISR_TRUNK_F32CONV', '1')
-    y2, _, _ = E.conv_forward(p, op, bias=ref.bias, stats=True)
-    assert torch.equal(y2, res['1'][0])
+    E.set_precision(precision)
+    try:
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 64, 3, 1, 1))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        assert not p.kinds[0]
+        xd = nhwc(x).cuda()
+        if pro == 'none':
+            op = E.Operand.plain(xd)
+        elif pro == 'act':
+            op = E.Operand.act(xd, slope.cuda())
+        else:
+            op = E.Operand.affine_act(xd, sc.cuda(), sh.cuda(), slope.cuda())
+        res = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_TRUNK_F32CONV', sw)
+            y, sp, cp = E.conv_forward(p, op, bias=ref.bias, stats=True)
+            res[sw] = (y, sp, cp)
+        assert res['1'][1].shape[0] <= min(res['0'][1].shape[0], 128)            # one row per pair of workgroups, not per tile
+        assert maxrel(nchw(res['1'][0]), y_ref) < tol
+        assert maxrel(res['1'][0], res['0'][0]) < tol
+        if precision == 'bf16x3':
+            assert not torch.equal(res['1'][0], res['0'][0])                      # (the split contraction did run)
+        t1, m1, v1 = _merged_stats(res['1'][1], res['1'][2])
+        t0, m0, v0 = _merged_stats(res['0'][1], res['0'][2])
+        assert t1 == t0 == n * h * w
+        assert maxrel(m1, m0) < tol and maxrel(v1, v0) < tol
+        assert maxrel(m1, y_ref.mean(dim=(0, 2, 3))) < tol and maxrel(v1, y_ref.var(dim=(0, 2, 3), unbiased=False)) < tol
+        monkeypatch.setenv('SISR_TRUNK_F32CONV', '1')
+        y2, _, _ = E.conv_forward(p, op, bias=ref.bias, stats=True)
+        assert torch.equal(y2, res['1'][0])
+    finally:
+        E.set_precision('fp32')
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('pro,res', [('bnbwd', False), ('bnbwd', True), ('bnact_bwd', True), ('bnact_bwd', False)])
 @pytest.mark.parametrize('shape', TRUNK_SHAPES)
-def test_trunk_kernel_fp32_data_gradient_role(E, L, shape, pro, res, monkeypatch):
+def test_trunk_kernel_fp32_data_gradient_role(E, L, shape, pro, res, precision, monkeypatch):
     """conv_trunk_f32.hip, data-gradient role: two-tensor BatchNorm-backward prologue (with / without the activation),
     skip gradient added in the epilogue -- against the generic fp32 kernel and against conv_transpose2d in double"""
     n, h, w = _walk(shape, monkeypatch)
@@ -703,21 +715,24 @@ def test_trunk_kernel_fp32_data_gradient_role(E, L, shape, pro, res, monkeypatch
         gg = torch.where(bc(ks) * c + bc(kt) > 0, g_in, 0.2 * g_in)
     dy_ref = bc(qa) * gg + bc(qb) * c + bc(qd)
     out_ref = F.conv_transpose2d(dy_ref.double(), wt.double(), padding=1) + (skip.double() if res else 0.0)
-    E.set_precision('fp32')
-    ref = FakeConv(wt.cuda(), None, E.ConvGeom(64, 64, 3, 1, 1))
-    p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
-    gd, cd = nhwc(g_in).cuda(), nhwc(c).cuda()
-    kw = dict(pa=qa.cuda(), pb=qb.cuda(), pd=qd.cuda())
-    if pro == 'bnact_bwd':
-        kw.update(ps=ks.cuda(), pt=kt.cuda(), slope=slope.cuda())
-    op = E.Operand(gd, tuple(cd.shape), pro=L.PRO_BNACT_BWD if pro == 'bnact_bwd' else L.PRO_BNBWD, x2=cd, **kw)
-    rd = nhwc(skip).cuda() if res else None
-    out = {}
-    for sw in ('1', '0'):
-        monkeypatch.setenv('SISR_TRUNK_F32CONV', sw)
-        out[sw] = E.conv_dgrad(p, op, res=rd)
-    assert maxrel(nchw(out['1']), out_ref) < 1e-5
-    assert maxrel(out['1'], out['0']) < 1e-5
+    E.set_precision(precision)
+    try:
+        ref = FakeConv(wt.cuda(), None, E.ConvGeom(64, 64, 3, 1, 1))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        gd, cd = nhwc(g_in).cuda(), nhwc(c).cuda()
+        kw = dict(pa=qa.cuda(), pb=qb.cuda(), pd=qd.cuda())
+        if pro == 'bnact_bwd':
+            kw.update(ps=ks.cuda(), pt=kt.cuda(), slope=slope.cuda())
+        op = E.Operand(gd, tuple(cd.shape), pro=L.PRO_BNACT_BWD if pro == 'bnact_bwd' else L.PRO_BNBWD, x2=cd, **kw)
+        rd = nhwc(skip).cuda() if res else None
+        out = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_TRUNK_F32CONV', sw)
+            out[sw] = E.conv_dgrad(p, op, res=rd)
+        assert maxrel(nchw(out['1']), out_ref) < SPLIT_TOL[precision]
+        assert maxrel(out['1'], out['0']) < SPLIT_TOL[precision]
+    finally:
+        E.set_precision('fp32')
 
 
 @pytest.mark.parametrize('pro,res,act', [('bnbwd', True, False), ('bnact_bwd', True, True), ('bnbwd', False, True)])

@@ -26,6 +26,10 @@ else:
     ck = (t[:, 61] - t[:, 60]) / 10e-3 / ((t[:, 63] - t[:, 0]) * 100.0)      # raw ticks / (us x 100 ticks per us)
 print('in-kernel shader clock (s_memtime / s_memrealtime): median %.3f GHz' % (float(np.median(ck)) / 10.0))
 print('prologue (weights to registers / first tile staged, barrier) +%.2f' % (t[:, 4] - t[:, 0]).mean())
+if prec != 'fp32' and os.environ.get('ROLE', 'fwd') == 'fwd':
+    rel = lambda k: (t[:, k] - t[:, 0]).mean()
+    print('  consumer: weight loads issued +%.2f, landed +%.2f; producer (wave 4): set up +%.2f, two tiles issued +%.2f, first tile in LDS +%.2f' % (
+        rel(2), rel(58), rel(64), rel(65), rel(66)))
 for it in range(8):
     b = 4 + 6 * it
     ok = t[:, b + 5] > 0
