@@ -245,8 +245,8 @@ def kernel_rooflines(device, precision, iters=40, only=None):
                  'wgrad': 'wgrad_trunk_kernel + slab_reduce_kernel (trunk 3x3 64->64)'}
         if os.environ.get('SISR_TRUNK_WGRAD', '1') == '0':
             names['wgrad'] = 'wgrad_mfma_bf16_kernel + slab_reduce_kernel (trunk 3x3 64->64)'
-    if precision == 'fp32' and os.environ.get('SISR_TRUNK', '1') != '0':
-        # fp32 tensors: the persistent exact-fp32 kernels (conv_trunk_f32.hip, wgrad_trunk_f32.hip)
+    if precision in ('fp32', 'bf16x3') and os.environ.get('SISR_TRUNK', '1') != '0':
+        # fp32 tensors: the persistent fp32-tensor kernels (conv_trunk_f32.hip, wgrad_trunk_f32.hip)
         if os.environ.get('SISR_TRUNK_F32CONV', '1') != '0':
             names['fwd'] = 'conv_trunk_f32_kernel (trunk 3x3 64->64, forward role)'
             names['dgrad'] = 'conv_trunk_f32_kernel (trunk 3x3 64->64, data-gradient role)'
@@ -257,7 +257,7 @@ def kernel_rooflines(device, precision, iters=40, only=None):
         roles = {r: v for r, v in roles.items() if r in only}
     for role, (fn, per_step, nbytes) in roles.items():
         ms = _time_launches(fn, iters)
-        if precision == 'bf16':
+        if precision in ('bf16', 'bf16x3'):
             achieved = nbytes / (ms * 1e-3) / 1e9
             traffic, src = _recorded_traffic('%s_%s' % (fam, role))
             rec = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
@@ -526,7 +526,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for rehearsals)')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying HIP graphs')
-    ap.add_argument('--precision', choices=['both', 'fp32', 'bf16'], default=os.environ.get('SISR_BENCH_PRECISION', 'both'),
+    ap.add_argument('--precision', choices=['both', 'fp32', 'bf16x3', 'bf16'], default=os.environ.get('SISR_BENCH_PRECISION', 'both'),
                     help='both (default): fp32 parity build at top level + bf16 build as perf_build; or one build only')
     ap.add_argument('--configs', default='all', help="BASELINE.json configs timed as one-GPU iteration rates (N = 1 only): "
                     "'all', 'none' or a comma list of cfg2,cfg3,cfg4,cfg5")

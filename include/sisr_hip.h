@@ -147,7 +147,7 @@ typedef struct SisrWgradDesc {
     int32_t grid_x, n_slabs, slab_elems, lds_bytes;
     uint32_t m_tiles_x, m_tiles_y, m_iw, m_twp, m_kw;   /* bf16 kernel: reciprocals as in SisrConvPlan */
     int32_t x_bf16, g_bf16;                  /* storage type of x1/x2 and of g1/g2 (0: fp32, 1: bf16) */
-    int32_t pad_;
+    int32_t mfma_split;                      /* fp32 operands, trunk geometry: as SisrConvDesc.mfma_split */
     int64_t slab_stride;                     /* set by the caller after planning              */
 } SisrWgradDesc;
 

@@ -57,7 +57,7 @@ class WgradDesc(C.Structure):
                                      'NJ', 'NP', 'NT', 'TSTEP', 'TVALID',
                                      'grid_x', 'n_slabs', 'slab_elems', 'lds_bytes')] +
                 [(n, C.c_uint32) for n in ('m_tiles_x', 'm_tiles_y', 'm_iw', 'm_twp', 'm_kw')] +
-                [('x_bf16', _i32), ('g_bf16', _i32), ('pad_', _i32)] +
+                [('x_bf16', _i32), ('g_bf16', _i32), ('mfma_split', _i32)] +
                 [('slab_stride', _i64)])
 
 

@@ -17,6 +17,7 @@
 // Slab layout as the generic fp32 kernel's (conv_wgrad.hip): [chunk][filter row][s * 33 + ci][64 co] + bias row, so the
 // reduction and un-packing kernels are shared.  One slab per workgroup.
 #include "sisr_dev.h"
+#include "sisr_bf16_stage.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -31,6 +32,11 @@
 #define WF_DBYTES (WF_TH * WF_TW * WF_PB)   // 16384
 #define WF_XITEMS ((WF_NPIX * 16 + 255) / 256)   // 16-byte items (4 channels) per producer thread: 7
 #define WF_THREADS 512
+// split build (SisrWgradDesc.mfma_split): every fp32 value in LDS as a (hi, lo) pair of bf16 -- a pixel is [64 hi][64 lo] plus
+// 32 bytes, so that the 4 pixel rows of a transposing read sit 8 banks apart
+#define WS_PB 288
+#define WS_XBYTES (WF_NPIX * WS_PB)         // 31104
+#define WS_DBYTES (WF_TH * WF_TW * WS_PB)   // 18432
 #define WF_PS 33                            // generic fp32 plan: krow = s * PS + ci
 #define WF_KROWP 100
 
@@ -69,7 +75,32 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wf_rsrc(const void* p, unsigne
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
-template <int GPRO>
+// two fp32 values -> their bf16 heads (round to nearest even) and the bf16 of what the heads leave: x = hi + lo up to 2^-17 |x|
+__device__ __forceinline__ void wf_split2(float v0, float v1, unsigned& hw, unsigned& lw) {
+    const f32x2 v = {v0, v1};
+    hw = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {v0 - __uint_as_float(hw << 16), v1 - __uint_as_float(hw & 0xFFFF0000u)};
+    lw = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+__device__ __forceinline__ void wf_store_split(unsigned char* dst, const f32x4& o) {
+    unsigned h0, l0, h1, l1;
+    wf_split2(o[0], o[1], h0, l0);
+    wf_split2(o[2], o[3], h1, l1);
+    const u32x2 hw = {h0, h1}, lw = {l0, l1};
+    *reinterpret_cast<u32x2*>(dst) = hw;
+    *reinterpret_cast<u32x2*>(dst + 128) = lw;
+}
+// K = 16 pixels of one channel per lane half: two transposing reads (4 pixel rows each) from a pixel-major split image
+__device__ __forceinline__ bf16x8 ws_frag(const unsigned char* p) {
+    const s16x4 lo = lds_tr16(reinterpret_cast<const __bf16*>(p)), hi = lds_tr16(reinterpret_cast<const __bf16*>(p + 4 * WS_PB));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// SPLIT: the same kernel with the contraction on the bf16 matrix instruction (v_mfma_f32_32x32x16_bf16: one K step = the 16
+// pixels of a tile row) as hi*hi + hi*lo + lo*hi over (hi, lo) bf16 pairs of both fp32 operands: 108 MFMAs of 32 cycles per
+// tile and wave instead of 288 of 64.  The producers split while they stage; the operands are fetched with transposing reads
+// as in wgrad_trunk.hip.  Tensors in HBM, prologue arithmetic, bias sums, accumulation and the slab are the fp32 kernel's.
+template <int GPRO, bool SPLIT>
 __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WTrunkF32Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];        // [2 buffers][x halo image | dy image]
 
@@ -87,6 +118,7 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         return (unsigned)(((n * a.H + ty * WF_TH) * a.W + tx * WF_TW) * 256);
     };
     float* sl = a.slab + (int64_t)blockIdx.x * a.slab_stride;
+    constexpr int XB = SPLIT ? WS_XBYTES : WF_XBYTES, BUF = SPLIT ? WS_XBYTES + WS_DBYTES : WF_XBYTES + WF_DBYTES, PB = SPLIT ? WS_PB : WF_PB;
     // (accounting marks of thread 0, a consumer: 4 = role state ready, 5 = first barrier passed, 6 = tile loop done, 7 = end)
     if (!consumer) {
         // ---- producers: both operands of tile T + 1 while the consumers multiply tile T ------------------------------------
@@ -120,7 +152,7 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         }
         const bool last_beyond = m0 + 16 * (WF_XITEMS - 1) >= WF_NPIX;
         const int grel0 = ((m0 >> 4) * a.W + (m0 & 15)) * 256 + quad * 16;   // tile pixel m0 + 16 k: one row further down per item
-        const int xlds0 = m0 * WF_PB + quad * 16, glds0 = WF_XBYTES + m0 * WF_PB + quad * 16;
+        const int xlds0 = m0 * PB + quad * (SPLIT ? 8 : 16), glds0 = XB + m0 * PB + quad * (SPLIT ? 8 : 16);
 
         // two staging register sets: the loads of tile T + 2 are in flight while tile T + 1 is transformed and written to LDS
         // (a tile lasts ~8 us of MFMAs; loading synchronously inside that window left the consumers waiting at 12 % of their
@@ -151,14 +183,17 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
             }
         };
         auto commit = [&](const Stage& st, int b) {
-            unsigned char* img = lds + b * (WF_XBYTES + WF_DBYTES);
+            unsigned char* img = lds + b * BUF;
             // x: lrelu(a x + d) (a = 1, d = 0, slope = 1 degenerate to ACT / NONE), zero outside the image
 #pragma unroll
             for (int k = 0; k < WF_XITEMS; ++k) {
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (st.okm >> k) & 1u ? lrelu(ka[j] * st.sx[k][j] + kd[j], xslope) : 0.f;
-                if (k < WF_XITEMS - 1 || !last_beyond) *reinterpret_cast<f32x4*>(img + xlds0 + k * 16 * WF_PB) = o;
+                if (k < WF_XITEMS - 1 || !last_beyond) {
+                    if constexpr (SPLIT) wf_store_split(img + xlds0 + k * 16 * PB, o);
+                    else *reinterpret_cast<f32x4*>(img + xlds0 + k * 16 * PB) = o;
+                }
             }
             // gradient: BatchNorm backward (through the activation for BNACT_BWD); the bias gradient is summed on the way
 #pragma unroll
@@ -172,7 +207,8 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
                     o[j] = qa[j] * g + qb[j] * bx + qd[j];
                 }
                 bsum += o;
-                *reinterpret_cast<f32x4*>(img + glds0 + k * 16 * WF_PB) = o;
+                if constexpr (SPLIT) wf_store_split(img + glds0 + k * 16 * PB, o);
+                else *reinterpret_cast<f32x4*>(img + glds0 + k * 16 * PB) = o;
             }
         };
 
@@ -212,7 +248,37 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         WFA_MARK(5);
         WFA_DECL;
         int cur = 0;
+        // (SPLIT) transposing-read lane roles: 16-lane group grp -> (channel half grp & 1, pixel half grp >> 1 of the 16-pixel K
+        // step); inside the group lane 4q + p addresses (pixel row q, channels 4p .. 4p + 3)
+        const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+        const int rd_pix = (8 * (grp >> 1) + tq) * WS_PB + (16 * (grp & 1) + 4 * tp) * 2;
         for (int T = blockIdx.x; T < a.total; T += gridDim.x, cur ^= 1) {
+            if constexpr (SPLIT) {
+                // halo rows R = 0 .. 5: the three column shifts of row R against the gradient rows R, R - 1, R - 2; small terms first
+                const unsigned char* xs = lds + cur * BUF + rd_pix + 64 * gq;
+                const unsigned char* ds = lds + cur * BUF + XB + rd_pix + 64 * h;
+                bf16x8 dyh[WF_TH], dyl[WF_TH];
+#pragma unroll
+                for (int R = 0; R < WF_IH; ++R) {
+                    if (R < WF_TH) { dyh[R] = ws_frag(ds + R * 16 * WS_PB); dyl[R] = ws_frag(ds + R * 16 * WS_PB + 128); }
+                    bf16x8 xh[3], xl[3];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) { xh[kx] = ws_frag(xs + (R * WF_IW + kx) * WS_PB); xl[kx] = ws_frag(xs + (R * WF_IW + kx) * WS_PB + 128); }
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int r = R - ky;
+                        if (r < 0 || r >= WF_TH) continue;
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[kx], dyh[r], acc[ky * 3 + kx], 0, 0, 0);
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[kx], dyl[r], acc[ky * 3 + kx], 0, 0, 0);
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[kx], dyh[r], acc[ky * 3 + kx], 0, 0, 0);
+                        }
+                    }
+                }
+                WFA_SYNC();
+                continue;
+            }
             const unsigned char* xb = lds + cur * (WF_XBYTES + WF_DBYTES) + xoff;
             const unsigned char* db = lds + cur * (WF_XBYTES + WF_DBYTES) + doff;
             // halo row R, K step s (pixels 2 s, 2 s + 1 of the row): the three column shifts of the x row against the
@@ -296,14 +362,18 @@ extern "C" int sisr_wgrad_f32_slabs(const SisrWgradDesc* d) {
     return sisr_wgrad_toimage_f32_eligible(d) ? sisr_wgrad_toimage_slabs(d) : d->n_slabs;
 }
 
-template <int GPRO>
-static int launch_wf(const WTrunkF32Args& a, int grid, hipStream_t st) {
-    constexpr int lds_bytes = 2 * (WF_XBYTES + WF_DBYTES);
+template <int GPRO, bool SPLIT>
+static int launch_wf_t(const WTrunkF32Args& a, int grid, hipStream_t st) {
+    constexpr int lds_bytes = SPLIT ? 2 * (WS_XBYTES + WS_DBYTES) : 2 * (WF_XBYTES + WF_DBYTES);
     static SisrLdsCap cap;
-    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&wgrad_trunk_f32_kernel<GPRO>), lds_bytes)) return e;
-    hipLaunchKernelGGL((wgrad_trunk_f32_kernel<GPRO>), dim3(grid), dim3(WF_THREADS), lds_bytes, st, a);
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&wgrad_trunk_f32_kernel<GPRO, SPLIT>), lds_bytes)) return e;
+    hipLaunchKernelGGL((wgrad_trunk_f32_kernel<GPRO, SPLIT>), dim3(grid), dim3(WF_THREADS), lds_bytes, st, a);
     SISR_CHECK_LAUNCH();
     return 0;
+}
+template <int GPRO>
+static int launch_wf(const WTrunkF32Args& a, bool split, int grid, hipStream_t st) {
+    return split ? launch_wf_t<GPRO, true>(a, grid, st) : launch_wf_t<GPRO, false>(a, grid, st);
 }
 
 // called by sisr_conv2d_wgrad_f32 for eligible descriptors
@@ -322,6 +392,6 @@ int sisr_wgrad_trunk_f32_launch(const SisrWgradDesc* d, hipStream_t st) {
     a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);
     a.xpro = d->pro_mode;
     const int grid = wf_grid(d);
-    if (d->gpro_mode == SISR_PRO_BNBWD) return launch_wf<SISR_PRO_BNBWD>(a, grid, st);
-    return launch_wf<SISR_PRO_BNACT_BWD>(a, grid, st);
+    if (d->gpro_mode == SISR_PRO_BNBWD) return launch_wf<SISR_PRO_BNBWD>(a, d->mfma_split != 0, grid, st);
+    return launch_wf<SISR_PRO_BNACT_BWD>(a, d->mfma_split != 0, grid, st);
 }

@@ -581,6 +581,7 @@ def conv_wgrad(prep, x_op, dy_op, defer=None):
     stride = g.slab_stride
     x_op.fill(g)
     dy_op.fill(g, g=True)
+    g.mfma_split = mfma_split()
     n_slabs = (lib.sisr_wgrad_bf16_slabs if prep.kinds[2] else lib.sisr_wgrad_f32_slabs)(C.byref(g))
     slab = torch.empty((n_slabs, stride), dtype=torch.float32, device=dev)
     g.slab = slab.data_ptr()

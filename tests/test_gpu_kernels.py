@@ -576,12 +576,13 @@ def test_trunk_kernel_weight_gradient_role(E, L, shape, xpro, gpro, monkeypatch)
         E.set_precision('fp32')
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('xpro,gpro', [('none', 'bnbwd'), ('act', 'bnact_bwd'), ('affine_act', 'bnbwd'), ('affine_act', 'bnact_bwd')])
 @pytest.mark.parametrize('shape', [(2, 12, 16)] + TRUNK_SHAPES[1:])
-def test_trunk_kernel_weight_gradient_role_fp32(E, L, shape, xpro, gpro, monkeypatch):
-    """wgrad_trunk_f32.hip (parity build: fp32 tensors, exact fp32 MFMA, persistent accumulators, 4 x 16 tiles) against
-    the generic fp32 weight-gradient kernel on the same lazy operands and against autograd: packed gradient, un-packed
-    weight gradient, bias gradient, bit-identical replay"""
+def test_trunk_kernel_weight_gradient_role_fp32(E, L, shape, xpro, gpro, precision, monkeypatch):
+    """wgrad_trunk_f32.hip (fp32 tensors, persistent accumulators, 4 x 16 tiles; 'fp32': exact fp32 MFMA, 'bf16x3': bf16 MFMA
+    over hi / lo pairs of both fp32 operands) against the generic fp32 weight-gradient kernel on the same lazy operands and
+    against autograd: packed gradient, un-packed weight gradient, bias gradient, bit-identical replay"""
     n, h, w = _walk(shape, monkeypatch)
     bc = lambda v: v[None, :, None, None]
     x = _rand((n, 64, h, w), 111) * 2.0
@@ -603,39 +604,44 @@ def test_trunk_kernel_weight_gradient_role_fp32(E, L, shape, xpro, gpro, monkeyp
     dy_ref = bc(qa) * gg + bc(qb) * c + bc(qd)
     wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
     (F.conv2d(xin.double(), wr.double(), br.double(), padding=1) * dy_ref.double()).sum().backward()
-    E.set_precision('fp32')
-    ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 64, 3, 1, 1))
-    p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
-    assert not p.kinds[2]
-    xd = nhwc(x).cuda()
-    if xpro == 'none':
-        x_op = E.Operand.plain(xd)
-    elif xpro == 'act':
-        x_op = E.Operand.act(xd, slope.cuda())
-    else:
-        x_op = E.Operand.affine_act(xd, sc.cuda(), sh.cuda(), slope.cuda())
-    gd, cd = nhwc(g_in).cuda(), nhwc(c).cuda()
-    kw = dict(pa=qa.cuda(), pb=qb.cuda(), pd=qd.cuda())
-    if gpro == 'bnact_bwd':
-        kw.update(ps=ks.cuda(), pt=kt.cuda(), slope=slope.cuda())
-    dy_op = E.Operand(gd, tuple(cd.shape), pro=L.PRO_BNACT_BWD if gpro == 'bnact_bwd' else L.PRO_BNBWD, x2=cd, **kw)
-    grads = {}
-    for sw in ('1', '0'):
-        monkeypatch.setenv('SISR_TRUNK_WGRAD', sw)
-        red = E.conv_wgrad(p, x_op, dy_op)
+    E.set_precision(precision)
+    try:
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 64, 3, 1, 1))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        assert not p.kinds[2]
+        xd = nhwc(x).cuda()
+        if xpro == 'none':
+            x_op = E.Operand.plain(xd)
+        elif xpro == 'act':
+            x_op = E.Operand.act(xd, slope.cuda())
+        else:
+            x_op = E.Operand.affine_act(xd, sc.cuda(), sh.cuda(), slope.cuda())
+        gd, cd = nhwc(g_in).cuda(), nhwc(c).cuda()
+        kw = dict(pa=qa.cuda(), pb=qb.cuda(), pd=qd.cuda())
+        if gpro == 'bnact_bwd':
+            kw.update(ps=ks.cuda(), pt=kt.cuda(), slope=slope.cuda())
+        dy_op = E.Operand(gd, tuple(cd.shape), pro=L.PRO_BNACT_BWD if gpro == 'bnact_bwd' else L.PRO_BNBWD, x2=cd, **kw)
+        grads = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_TRUNK_WGRAD', sw)
+            red = E.conv_wgrad(p, x_op, dy_op)
+            wg = E.WeightGradBatch()
+            wg.add(p, red)
+            grads[sw] = wg.run()[id(ref)] + (red,)
+        for k in (0, 1):
+            assert maxrel(grads['1'][k], grads['0'][k]) < 2 * SPLIT_TOL[precision]   # fp32: same products, different summation order
+        if precision == 'bf16x3':
+            assert not torch.equal(grads['1'][0], grads['0'][0])                      # (the split contraction did run)
+        assert maxrel(grads['1'][0], wr.grad) < 1e-4, 'wgrad'
+        assert maxrel(grads['1'][1], br.grad) < 1e-4, 'bias grad'
+        monkeypatch.setenv('SISR_TRUNK_WGRAD', '1')
+        red2 = E.conv_wgrad(p, x_op, dy_op)
         wg = E.WeightGradBatch()
-        wg.add(p, red)
-        grads[sw] = wg.run()[id(ref)] + (red,)
-    for k in (0, 1):
-        assert maxrel(grads['1'][k], grads['0'][k]) < 2e-5          # same fp32 products, different summation order
-    assert maxrel(grads['1'][0], wr.grad) < 1e-4, 'wgrad'
-    assert maxrel(grads['1'][1], br.grad) < 1e-4, 'bias grad'
-    monkeypatch.setenv('SISR_TRUNK_WGRAD', '1')
-    red2 = E.conv_wgrad(p, x_op, dy_op)
-    wg = E.WeightGradBatch()
-    wg.add(p, red2)
-    gw2, gb2 = wg.run()[id(ref)]
-    assert torch.equal(gw2, grads['1'][0]) and torch.equal(gb2, grads['1'][1])
+        wg.add(p, red2)
+        gw2, gb2 = wg.run()[id(ref)]
+        assert torch.equal(gw2, grads['1'][0]) and torch.equal(gb2, grads['1'][1])
+    finally:
+        E.set_precision('fp32')
 
 
 # the split build's contraction (SisrConvDesc.mfma_split): every fp32 operand as hi + lo bf16, good to 2^-17 = 7.6e-6 relative

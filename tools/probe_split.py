@@ -23,8 +23,9 @@ for prec in ('fp32', 'bf16x3'):
     ms = bench._time_launches(lambda: E.conv_forward(p, op, bias=bias, stats=True, out=out), 40)
     dy = E.Operand(x, tuple(c.shape), pro=L.PRO_BNACT_BWD, x2=c, pa=sc, pb=sh, pd=sh, ps=sc, pt=sh, slope=slope)
     msd = bench._time_launches(lambda: E.conv_dgrad(p, dy, res=c), 40)
-    outs[prec] = (out.clone(), E.conv_dgrad(p, dy, res=c))
-    print('%-7s fwd %.2f us  dgrad %.2f us' % (prec, ms * 1e3, msd * 1e3))
-for i, nm in enumerate(('fwd', 'dgrad')):
+    msw = bench._time_launches(lambda: E.conv_wgrad(p, op, dy), 40)
+    outs[prec] = (out.clone(), E.conv_dgrad(p, dy, res=c), E.conv_wgrad(p, op, dy))
+    print('%-7s fwd %.2f us  dgrad %.2f us  wgrad + slab sum %.2f us' % (prec, ms * 1e3, msd * 1e3, msw * 1e3))
+for i, nm in enumerate(('fwd', 'dgrad', 'wgrad')):
     a, b = outs['fp32'][i], outs['bf16x3'][i]
     print(nm, 'split vs exact: max |diff| / max |ref| = %.2e' % float((a - b).abs().max() / b.abs().max()))
