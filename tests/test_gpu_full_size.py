@@ -17,6 +17,7 @@ Two kinds of checks:
 import pytest
 import torch
 
+from conftest import PARITY_BUILDS
 from gpu_helpers import pkg
 from helpers import grads_close, oracle_fwd_bwd, rel_err
 
@@ -159,8 +160,7 @@ def _oracle_compare(net, cfg, state, x, r):
 
 def _generator_case(lr, init, slopes=None):
     from oracle import init as oinit
-    E, mg = pkg('engine'), pkg('model_generator')
-    E.set_precision('fp32')
+    mg = pkg('model_generator')                                 # (the build under test is set by the parity_build fixture)
     torch.manual_seed(0)
     net = mg.Generator(16, 64, 256, [2], use_sn=True).cuda().train()
     if init == 'default':
@@ -179,8 +179,9 @@ def _generator_case(lr, init, slopes=None):
     return net, {'kind': 'generator', 'list_scales': [2], 'n_suffix': 0}, state, x, r
 
 
+@pytest.mark.parametrize('parity_build', PARITY_BUILDS, indirect=True)
 @pytest.mark.parametrize('lr,init', [(48, 'default'), (96, 'synthetic')])
-def test_full_size_generator_values_at_1e3_with_nearly_linear_activations(lr, init):
+def test_full_size_generator_values_at_1e3_with_nearly_linear_activations(lr, init, parity_build):
     """model_generator.py:86-101 at config.py:79-80's sizes -- Generator(16, 64, 256, [2], use_sn=True), B16, LR 48
     (cfg2's generator: 288 tiles) and LR 96 (the headline workload: 1,152 tiles = 5 / 9 per workgroup, the schedule
     no small case reaches) -- against the CPU oracle, EVERY tensor at 1e-3 relative: output, input gradient, all 140
@@ -246,8 +247,9 @@ def _flip_aware_compare(net, cfg, state, x, r, strict_keys=()):
     return out
 
 
+@pytest.mark.parametrize('parity_build', PARITY_BUILDS, indirect=True)
 @pytest.mark.parametrize('lr,init', [(48, 'default'), (96, 'synthetic')])
-def test_full_size_generator_with_the_references_activations(lr, init):
+def test_full_size_generator_with_the_references_activations(lr, init, parity_build):
     """the same sizes with the reference's own activations (PReLU 0.25 from the default init / 0.1-0.4 synthetic):
     see _flip_aware_compare.  The last conv and the upscale conv sit behind one PReLU only; everything is held to the
     flip-aware bounds, the forward to 1e-3."""

@@ -3,6 +3,7 @@ from the reference modules, within BASELINE.json's 1e-3 relative fp32 tolerance.
 import pytest
 import torch
 
+from conftest import PARITY_BUILDS
 from gpu_helpers import pkg
 from helpers import GEN_CASES, PROG_CASES, grads_close, load_case, rel_err
 
@@ -26,8 +27,9 @@ def build(cfg):
     return g
 
 
+@pytest.mark.parametrize('parity_build', PARITY_BUILDS, indirect=True)
 @pytest.mark.parametrize('name', GEN_CASES + PROG_CASES)
-def test_generator_matches_reference_golden(name):
+def test_generator_matches_reference_golden(name, parity_build):
     z, cfg, state, grads, after = load_case(name)
     net = build(cfg)
     net.load_state_dict(state, strict=True)
@@ -50,7 +52,8 @@ def test_generator_matches_reference_golden(name):
         assert rel_err(net(x).cpu(), z['out_eval']) < TOL      # running statistics, no power iteration
 
 
-def test_full_depth_generator_matches_reference_golden():
+@pytest.mark.parametrize('parity_build', PARITY_BUILDS, indirect=True)
+def test_full_depth_generator_matches_reference_golden(parity_build):
     """16 residual blocks (34 stacked conv+BatchNorm layers, spectral norm on every conv; the benchmark's own
     architecture, config.py:79-80) at B2, LR 16: out / grad_x / sampled parameter gradients / advanced SN+BN state /
     second training forward against vectors captured from the imported reference module, 1e-3 relative fp32"""
@@ -67,9 +70,21 @@ def test_full_depth_generator_matches_reference_golden():
     out = net(x)
     assert rel_err(out.detach().cpu(), z['out']) < TOL
     (out * torch.from_numpy(z['r']).cuda()).sum().backward()
-    assert rel_err(x.grad.cpu(), z['grad_x']) < TOL
     got, ref = sample({k: p.grad.detach().cpu() for k, p in net.named_parameters()})
-    assert grads_close(got, ref, TOL) == []
+    if parity_build == 'fp32':
+        assert rel_err(x.grad.cpu(), z['grad_x']) < TOL
+        assert grads_close(got, ref, TOL) == []
+    else:
+        # The split build's contractions carry 2^-17 operands: 3e-5 on the output after these 34 layers, against 5e-6 for the
+        # exact-fp32 kernels (tools/diag_full_depth.py).  That is enough for ONE pre-activation within 1e-5 of zero to take the
+        # other PReLU branch here, which moves the gradients in its receptive field: 1.49e-3 in max-norm on the input gradient
+        # (243 of 1,536 elements by more than 1e-4), i.e. this vector is NOT met at 1e-3 by this build -- it is held to the
+        # flip-sized bounds of test_gpu_full_size._flip_aware_compare instead (max-norm 5e-2, RMS 5e-3), and is the reason the
+        # exact-fp32 build stays the parity build of record.
+        gx, gx_ref = x.grad.cpu().double(), torch.from_numpy(z['grad_x']).double()
+        assert float((gx - gx_ref).abs().max() / gx_ref.abs().max()) < 5e-2
+        assert float((gx - gx_ref).pow(2).mean().sqrt() / gx_ref.pow(2).mean().sqrt()) < 5e-3
+        assert grads_close(got, ref, 5e-2) == []
     sd = net.state_dict()
     for k, v in after.items():
         assert rel_err(sd[k].cpu().double(), v.double()) < TOL, k

@@ -11,13 +11,14 @@ torch.cuda.synchronize()
 L = C.CDLL(os.environ['SISR_LIB'])
 slots = 128
 buf = np.zeros(512 * slots, dtype=np.uint64)
-reader = L.sisr_cftrace_read if prec == 'fp32' else (L.sisr_wttrace_read if os.environ.get('ROLE', 'fwd') == 'wgrad' else L.sisr_ttrace_read)
+f32t = prec in ('fp32', 'bf16x3')
+reader = L.sisr_cftrace_read if f32t else (L.sisr_wttrace_read if os.environ.get('ROLE', 'fwd') == 'wgrad' else L.sisr_ttrace_read)
 assert reader(buf.ctypes.data_as(C.c_void_p), C.c_int(buf.size)) == 0
 t = buf.reshape(512, slots).astype(np.int64) * 10e-3
 t = t[t[:, 0] > 0]
 t0 = t[:, 0].min()
 print('%d workgroups; kernel span %.2f us; lifetime avg %.2f; start spread %.2f' % (len(t), t[:, 63].max() - t0, (t[:, 63] - t[:, 0]).mean(), (t[:, 0] - t0).max()))
-if prec == 'fp32':
+if f32t:
     cb = np.zeros(512 * 2, dtype=np.uint64)
     assert L.sisr_cfclk_read(cb.ctypes.data_as(C.c_void_p), C.c_int(cb.size)) == 0
     cb = cb.reshape(512, 2).astype(np.int64)[:len(t)]
@@ -26,7 +27,7 @@ else:
     ck = (t[:, 61] - t[:, 60]) / 10e-3 / ((t[:, 63] - t[:, 0]) * 100.0)      # raw ticks / (us x 100 ticks per us)
 print('in-kernel shader clock (s_memtime / s_memrealtime): median %.3f GHz' % (float(np.median(ck)) / 10.0))
 print('prologue (weights to registers / first tile staged, barrier) +%.2f' % (t[:, 4] - t[:, 0]).mean())
-if prec != 'fp32' and os.environ.get('ROLE', 'fwd') == 'fwd':
+if not f32t and os.environ.get('ROLE', 'fwd') == 'fwd':
     rel = lambda k: (t[:, k] - t[:, 0]).mean()
     print('  consumer: weight loads issued +%.2f, landed +%.2f; producer (wave 4): set up +%.2f, two tiles issued +%.2f, first tile in LDS +%.2f' % (
         rel(2), rel(58), rel(64), rel(65), rel(66)))
