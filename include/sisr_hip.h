@@ -61,7 +61,9 @@ typedef struct SisrConvPlan {
     int32_t msub, nsub;             /* 32x32 MFMA sub-tiles per wave (M) / per block (N)     */
     int32_t lds_bytes;
     int32_t wpk_elems;              /* elements in the packed weight buffer                  */
-    int32_t variant;                /* kernel variant within a family; 0 (the only one) -- reserved        */
+    int32_t variant;                /* bf16 family, bit 0: the weight buffer carries the LANE-ORDER image of the persistent trunk
+                                       kernels behind the standard one (SisrWeightDesc.bf_f_lanes / bf_d_lanes); set by the caller
+                                       on the descriptor it launches, 0 after planning                      */
     /* bf16 family: reciprocals m = ceil(2^32 / d) (0 for d = 1) so that n / d = umulhi(n, m) for n, d < 2^16 --
      * the kernels' index arithmetic (tile id, tile row, LDS row) without integer division */
     uint32_t m_tiles_x, m_thw, m_tw, m_iw, m_wrow;
@@ -243,6 +245,11 @@ typedef struct SisrWeightDesc {
     int32_t bf_f_CK, bf_d_CK;   /* in-channel chunk of the bf16 images (32) */
     void *wbf_dcls[4];          /* bf16 images of the stride-2 parity classes (chunks of 32), or NULL: then wpk_dcls */
     int32_t bf_c_CoutPad[4];
+    /* trunk geometry (Cin = 64, 3x3, CoutPad % 64 == 0): also write, right behind wbf_fwd / wbf_dgrad (same size again), the image
+     * in the order the persistent trunk kernels load it -- [32-cout block][tap][k slice j: 16 in-channels][lane = kk * 32 + cout]
+     * x 8 bf16 (in-channels (j >> 1) * 32 + (j & 1) * 16 + 8 kk ..) -- so that a wave's 16-byte loads are contiguous (1 KB per
+     * instruction instead of 64 pieces 576 bytes apart: 1.1 us of every launch) */
+    int32_t bf_f_lanes, bf_d_lanes;
 } SisrWeightDesc;
 
 /* max_rows / max_cols: largest Cout and Cin*KH*KW over the table (the launch grids are sized from them) */

@@ -70,7 +70,8 @@ class WeightDesc(C.Structure):
                 [(n, _i32 * 4) for n in ('c_KH', 'c_KW', 'c_R0y', 'c_R0x', 'c_CK', 'c_PS', 'c_KROWP',
                                          'c_n_chunk', 'c_CoutPad')] +
                 [('wbf_fwd', _f), ('wbf_dgrad', _f), ('bf_f_CoutPad', _i32), ('bf_d_CoutPad', _i32),
-                 ('bf_f_CK', _i32), ('bf_d_CK', _i32), ('wbf_dcls', _f * 4), ('bf_c_CoutPad', _i32 * 4)])
+                 ('bf_f_CK', _i32), ('bf_d_CK', _i32), ('wbf_dcls', _f * 4), ('bf_c_CoutPad', _i32 * 4),
+                 ('bf_f_lanes', _i32), ('bf_d_lanes', _i32)])
 
 
 class WeightGradDesc(C.Structure):

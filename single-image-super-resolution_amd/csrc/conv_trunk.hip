@@ -90,6 +90,7 @@ struct TrunkArgs {
     const float *pa, *pb, *pd, *ps, *pt;  // per-channel prologue constants
     const float* slope_p; float slope;
     const void* wpk;                      // bf16 image [2 chunks][64 couts][9 taps][32 cin]
+    const void* wln;                      // the same weights in the consumers' load order (SisrWeightDesc.bf_f_lanes), or nullptr
     const float* bias;
     void* y;                              // bf16 NHWC [N][H][W][64]
     float *stat_part, *cnt_part;          // forward role: [grid][2][64], [grid]
@@ -191,9 +192,6 @@ __device__ __forceinline__ u32x4 trunk_apply8(u32x4 a, u32x4 b, const f32x8& ka,
 #ifndef TK_EARLY
 #define TK_EARLY 0
 #endif
-#ifndef SISR_ABLATE_WLOAD
-#define SISR_ABLATE_WLOAD 0
-#endif
 #ifndef TK_PFA
 #define TK_PFA 4                          // ... of the forward consumers' phases, in MFMAs (5 and more spill: 256 VGPRs are in use)
 #endif
@@ -246,23 +244,27 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     // (role state is set up INSIDE the role branches below: set up ahead of the split, every register of both roles
     // meets in one merge block and the allocator spills weights at load time)
     auto init_consumer = [&]() {
-        const __amdgpu_buffer_rsrc_t wrs = bf_rsrc(a.wpk, 2u * (unsigned)a.cout_pad * 9u * 32u * 2u);
-        const int co = 64 * cg + 32 * h + l31;                              // packed cout
+        const unsigned wbytes = 2u * (unsigned)a.cout_pad * 9u * 32u * 2u;
+        if (a.wln != nullptr) {
+            // lane-order image: [32-cout block 2 cg + h][tap][k slice][lane] x 16 bytes -- every load instruction is 1 KB contiguous
+            const __amdgpu_buffer_rsrc_t wrs = bf_rsrc(a.wln, wbytes);
+            const unsigned base = (unsigned)(((2 * cg + h) * 36 * 64 + lane) * 16);
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#if SISR_ABLATE_WLOAD == 1       // timing-only (wrong values): what fully coalesced weight loads would cost
-                const unsigned off = (unsigned)(((((cg * 2 + h) * 9 + t) * 4 + j) * 64 + lane) * 16);
-#else
-                const unsigned off = (unsigned)((((j >> 1) * a.cout_pad + co) * 9 + t) * 32 + (j & 1) * 16 + 8 * kk) * 2u;
-#endif
-#if SISR_ABLATE_WLOAD == 2       // timing-only: no weight loads at all
-                bw[t][j] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)off, (unsigned)lane, 1u, 2u});
-#else
-                bw[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
-#endif
-            }
+                for (int j = 0; j < 4; ++j)
+                    bw[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, base + (unsigned)((t * 4 + j) * 1024), 0, 0));
+        } else {
+            const __amdgpu_buffer_rsrc_t wrs = bf_rsrc(a.wpk, wbytes);
+            const int co = 64 * cg + 32 * h + l31;                              // packed cout
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned off = (unsigned)((((j >> 1) * a.cout_pad + co) * 9 + t) * 32 + (j & 1) * 16 + 8 * kk) * 2u;
+                    bw[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
+                }
+        }
         // A operand of sub-tile ms: lane (l31, kk) = pixel (tile row 4g + 2ms + (l31 >> 4), column l31 & 15), channels 8kk..
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) a_base[ms] = (4 * g + 2 * ms + (l31 >> 4)) * TK_RP + (l31 & 15) * TK_PSB + kk * 16;
@@ -655,15 +657,25 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_bwd_kernel(const Tru
     unsigned sok = 0;
 
     auto init_consumer = [&]() {
-        const __amdgpu_buffer_rsrc_t wrs = bf_rsrc(a.wpk, 2u * 64u * 9u * 32u * 2u);
         const int co = 32 * h + l31;
+        if (a.wln != nullptr) {
+            const __amdgpu_buffer_rsrc_t wrs = bf_rsrc(a.wln, 2u * 64u * 9u * 32u * 2u);
+            const unsigned base = (unsigned)((h * 36 * 64 + lane) * 16);
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned off = (unsigned)((((j >> 1) * 64 + co) * 9 + t) * 32 + (j & 1) * 16 + 8 * kk) * 2u;
-                bw[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
-            }
+                for (int j = 0; j < 4; ++j)
+                    bw[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, base + (unsigned)((t * 4 + j) * 1024), 0, 0));
+        } else {
+            const __amdgpu_buffer_rsrc_t wrs = bf_rsrc(a.wpk, 2u * 64u * 9u * 32u * 2u);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned off = (unsigned)((((j >> 1) * 64 + co) * 9 + t) * 32 + (j & 1) * 16 + 8 * kk) * 2u;
+                    bw[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
+                }
+        }
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) a_base[ms] = (4 * g + 2 * ms + (l31 >> 4)) * TK_RP + (l31 & 15) * TK_PSB + kk * 16;
         if (has_x) {
@@ -991,7 +1003,8 @@ int sisr_conv2d_trunk_launch(const SisrConvDesc* d, hipStream_t st) {
     a.fin.rm = d->fin_rm; a.fin.rv = d->fin_rv; a.fin.k = d->fin_k; a.fin.rows = d->fin_rows; a.fin.momentum = d->fin_momentum; a.fin.eps = d->fin_eps;
     a.x1 = d->x1; a.x2 = d->x2; a.x_out = d->x_out; a.pa = d->pa; a.pb = d->pb; a.pd = d->pd; a.ps = d->ps; a.pt = d->pt;
     a.slope_p = d->pro_slope_p; a.slope = d->pro_slope;
-    a.wpk = d->wpk; a.bias = d->bias; a.y = d->y; a.stat_part = d->stat_part; a.cnt_part = d->cnt_part;
+    a.wpk = d->wpk; a.bias = d->bias;
+    a.wln = (d->plan.variant & 1) ? static_cast<const char*>(static_cast<const void*>(d->wpk)) + (size_t)(d->Cout == 256 ? 256 : 64) * 1152 : nullptr; a.y = d->y; a.stat_part = d->stat_part; a.cnt_part = d->cnt_part;
     a.N = d->N; a.H = d->H; a.W = d->W;
     a.tiles_x = d->W / TK_TW; a.per_img = (d->H / TK_TH) * a.tiles_x; a.total = d->N * a.per_img;
     a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);

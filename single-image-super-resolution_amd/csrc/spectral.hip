@@ -194,6 +194,25 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
             }
             dst[e] = (__bf16)val;
         }
+        if (w.bf_f_lanes) {
+            // the same values in the persistent trunk kernels' load order (see SisrWeightDesc.bf_f_lanes), behind the image above
+            for (int64_t e = start; e < total; e += stride) {
+                unsigned tq = (unsigned)e;
+                const int el = (int)(tq & 7); tq >>= 3;
+                const int lane = (int)(tq & 63); tq >>= 6;
+                const int j = (int)(tq & 3); tq >>= 2;
+                const int tap = (int)(tq % 9);
+                const int cp = (int)(tq / 9) * 32 + (lane & 31);
+                const int ci = (j >> 1) * 32 + (j & 1) * 16 + 8 * (lane >> 5) + el;
+                const int r = tap / w.KW, sx = tap - r * w.KW;
+                float val = 0.f;
+                if (cp < w.Cout) {
+                    const int co = unpermute_cout(cp, w.Cout, w.shuffle2);
+                    val = w.w_orig[(((int64_t)co * w.Cin + ci) * w.KH + r) * w.KW + sx] * inv;
+                }
+                dst[total + e] = (__bf16)val;
+            }
+        }
     }
     if (w.wbf_dgrad) {
         __bf16* dst = reinterpret_cast<__bf16*>(w.wbf_dgrad);
@@ -213,6 +232,24 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
                 val = w.w_orig[(((int64_t)co * w.Cin + op) * w.KH + (w.KH - 1 - r)) * w.KW + (w.KW - 1 - sx)] * inv;
             }
             dst[e] = (__bf16)val;
+        }
+        if (w.bf_d_lanes) {
+            for (int64_t e = start; e < total; e += stride) {
+                unsigned tq = (unsigned)e;
+                const int el = (int)(tq & 7); tq >>= 3;
+                const int lane = (int)(tq & 63); tq >>= 6;
+                const int j = (int)(tq & 3); tq >>= 2;
+                const int tap = (int)(tq % 9);
+                const int op = (int)(tq / 9) * 32 + (lane & 31);
+                const int ip = (j >> 1) * 32 + (j & 1) * 16 + 8 * (lane >> 5) + el;
+                const int r = tap / w.KW, sx = tap - r * w.KW;
+                float val = 0.f;
+                if (op < w.Cin) {
+                    const int co = unpermute_cout(ip, w.Cout, w.shuffle2);
+                    val = w.w_orig[(((int64_t)co * w.Cin + op) * w.KH + (w.KH - 1 - r)) * w.KW + (w.KW - 1 - sx)] * inv;
+                }
+                dst[total + e] = (__bf16)val;
+            }
         }
     }
     // stride-2 data gradient: one packed image per output parity class (bf16 image for the bf16 kernels)

@@ -219,7 +219,18 @@ class ConvRef:
 
 class Prepared:
     """Per-forward products of sisr_weights_prepare for one conv (kept for the backward pass)."""
-    __slots__ = ('ref', 'plans', 'kinds', 'wpk_fwd', 'wpk_dgrad', 'sigma', 'u_used', 'v_used')
+    __slots__ = ('ref', 'plans', 'kinds', 'wpk_fwd', 'wpk_dgrad', 'sigma', 'u_used', 'v_used', 'lanes')
+
+
+def _trunk_lanes(gm, plan_f, plan_d, kinds):
+    """(forward, data-gradient): the bf16 weight buffer also gets the lane-order image of the persistent trunk kernels
+    (SisrWeightDesc.bf_f_lanes / bf_d_lanes) -- every 3x3 conv over 64 input channels whose packed couts come in blocks of 64"""
+    if os.environ.get('SISR_TRUNK_LANES', '1') == '0' or gm.k != 3:
+        return False, False
+    lf = bool(kinds[0]) and gm.cin == 64 and plan_f.plan.CK == 32 and plan_f.plan.CoutPad % 64 == 0
+    ld = (bool(kinds[1]) and plan_d is not None and not isinstance(plan_d, list) and gm.cout == 64 and gm.cin == 64
+          and plan_d.plan.CK == 32 and plan_d.plan.CoutPad == 64)
+    return lf, ld
 
 
 def prepare_weights(items, training, need_dgrad=True):
@@ -231,8 +242,9 @@ def prepare_weights(items, training, need_dgrad=True):
     metas = []
     for ref, n, h, w in items:
         f, d, g, kinds = ref.geom.plans(n, h, w)
+        lanes = _trunk_lanes(ref.geom, f, d, kinds)
         off_f = total
-        total += _align4((f.plan.wpk_elems + 1) // 2 if kinds[0] else f.plan.wpk_elems)   # bf16: 2 per float slot
+        total += _align4(((f.plan.wpk_elems + 1) // 2) * (2 if lanes[0] else 1) if kinds[0] else f.plan.wpk_elems)   # bf16: 2 per float slot
         off_d = None
         if need_dgrad and isinstance(d, list):
             off_d = []
@@ -242,7 +254,7 @@ def prepare_weights(items, training, need_dgrad=True):
                     total += _align4((cls[0].plan.wpk_elems + 1) // 2 if cls[3] else cls[0].plan.wpk_elems)
         elif need_dgrad and d is not None:
             off_d = total
-            total += _align4((d.plan.wpk_elems + 1) // 2 if kinds[1] else d.plan.wpk_elems)
+            total += _align4(((d.plan.wpk_elems + 1) // 2) * (2 if lanes[1] else 1) if kinds[1] else d.plan.wpk_elems)
         off_s = small
         rows_, cols_ = ref.geom.cout, ref.geom.cin * ref.geom.k * ref.geom.k
         small += 4 + (_align4(rows_) + _align4(cols_) if ref.u is not None else 0)
@@ -259,13 +271,14 @@ def prepare_weights(items, training, need_dgrad=True):
         gm = ref.geom
         p = Prepared()
         p.ref, p.plans, p.kinds = ref, (f, d, g), kinds
-        p.wpk_fwd = big[off_f:off_f + ((f.plan.wpk_elems + 1) // 2 if kinds[0] else f.plan.wpk_elems)]
+        p.lanes = _trunk_lanes(gm, f, d, kinds)
+        p.wpk_fwd = big[off_f:off_f + (((f.plan.wpk_elems + 1) // 2) * (2 if p.lanes[0] else 1) if kinds[0] else f.plan.wpk_elems)]
         if isinstance(off_d, list):
             p.wpk_dgrad = [None if o is None else
                            big[o:o + ((cls[0].plan.wpk_elems + 1) // 2 if cls[3] else cls[0].plan.wpk_elems)]
                            for o, cls in zip(off_d, d)]
         else:
-            p.wpk_dgrad = (big[off_d:off_d + ((d.plan.wpk_elems + 1) // 2 if kinds[1] else d.plan.wpk_elems)]
+            p.wpk_dgrad = (big[off_d:off_d + (((d.plan.wpk_elems + 1) // 2) * (2 if p.lanes[1] else 1) if kinds[1] else d.plan.wpk_elems)]
                            if off_d is not None else None)
         p.sigma = sm[off_s:off_s + 1]
         t = table[i]
@@ -273,10 +286,12 @@ def prepare_weights(items, training, need_dgrad=True):
         t.sigma = p.sigma.data_ptr()
         if kinds[0]:
             t.wbf_fwd, t.bf_f_CoutPad, t.bf_f_CK = p.wpk_fwd.data_ptr(), f.plan.CoutPad, f.plan.CK
+            t.bf_f_lanes = int(p.lanes[0])
         else:
             t.wpk_fwd = p.wpk_fwd.data_ptr()
         if kinds[1]:
             t.wbf_dgrad, t.bf_d_CoutPad, t.bf_d_CK = p.wpk_dgrad.data_ptr(), d.plan.CoutPad, d.plan.CK
+            t.bf_d_lanes = int(p.lanes[1] and off_d is not None)
         else:
             t.wpk_dgrad = None if isinstance(p.wpk_dgrad, list) else _ptr(p.wpk_dgrad)
         t.Cout, t.Cin, t.KH, t.KW = gm.cout, gm.cin, gm.k, gm.k
@@ -414,6 +429,7 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
     f.y_bf16, f.res_bf16 = _bf(out), _bf(res)
     f.epi_act = epi
     f.mfma_split = mfma_split()
+    f.plan.variant = int(prep.lanes[0])
     fin = op.fin
     if fin is not None and not fin.done:
         # deferred BatchNorm finalisation: by this conv when it runs on a persistent trunk kernel, else stand-alone first
@@ -508,6 +524,7 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
     d.wpk, d.bias, d.res, d.y = prep.wpk_dgrad.data_ptr(), None, _ptr(res), out.data_ptr()
     d.y_bf16, d.res_bf16 = _bf(out), _bf(res)
     d.mfma_split = mfma_split()
+    d.plan.variant = int(prep.lanes[1])
     part = None
     if bnb is not None:
         x, consts, slope = bnb
