@@ -89,6 +89,10 @@ struct CTrunkF32Args {
     int N, H, W;
     int tiles_x, per_img, total, streams;
     uint32_t m_tiles_x, m_per_img;
+    // forward role with Cout = 256 stored through PixelShuffle(2) (the generator's upscale conv, model_generator.py:43-48): eight
+    // blocks of 32 packed couts per pixel-tile stream (glog = 3) instead of two; packed cout 64 (2 i + j) + c is channel c of
+    // output pixel (2 y + i, 2 x + j)
+    int glog, cout_pad, shuffle;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t cf_rsrc(const void* p, unsigned bytes) {
@@ -119,7 +123,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool consumer = wave < 4;
     const int l31 = lane & 31, kk = lane >> 5;
-    const int hc = blockIdx.x & 1, stream = blockIdx.x >> 1;   // output-channel half, pixel-tile stream
+    const int hc = blockIdx.x & ((1 << a.glog) - 1), stream = blockIdx.x >> a.glog;   // block of 32 output channels, pixel-tile stream
     const unsigned tbytes = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * 256u;
     constexpr bool TWO = PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD || PRO == SISR_PRO_RES_AFFINE;
     constexpr bool SUM = PRO == SISR_PRO_RES_AFFINE;          // skip-sum prologue: lrelu(x1) + (a x2 + d), stored back once
@@ -149,7 +153,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             const int e = tid + it * CF_THREADS;
             const int ci = e & 31, s = (e >> 5) % 3, t2 = (e >> 5) / 3;        // t2 = (q * 3 + r) * 32 + co
             const int co = t2 & 31, qr = t2 >> 5;                               // qr = q * 3 + r
-            wv[it] = a.wpk[((int64_t)qr * 64 + 32 * hc + co) * CF_KROWP + s * CF_PS + ci];
+            wv[it] = a.wpk[((int64_t)qr * a.cout_pad + 32 * hc + co) * CF_KROWP + s * CF_PS + ci];
         }
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
@@ -306,17 +310,19 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
         // ---- consumers: wave w = tile rows 2 w, 2 w + 1 (32 pixels) x this workgroup's 32 couts -------------------------------
         // operand lane roles (sisr_dev.h; K order chosen here): A = x[pixel l31][ci = 16 kk + s], B = W[ci = 16 kk + s][co = l31];
         // accumulator register i of a lane = pixel mfma_row(i, lane) of the sub-tile, cout l31
-        const int co = 32 * hc + l31;
+        const int co = a.shuffle ? 32 * (hc & 1) + l31 : 32 * hc + l31;           // channel of the (stored) output tensor
+        const int ph = hc >> 1;                                                     // PixelShuffle phase (i, j) of this block
         // step s of a 32-channel slice: A = x[pixel l31][ci = 16 kk + s], B = W[ci = 16 kk + s][co = l31]
         // (SPLIT: step ks of a 32-channel slice is 16 channels, lane half kk multiplies channels 16 ks + 8 kk .. + 7: 16 bytes of the
         // hi half of the row, and the same 16 bytes of the lo half 64 bytes on)
         const int abase = SPLIT ? ((2 * wave + (l31 >> 4)) * CF_IW + (l31 & 15)) * CF_PSF * 4 + 16 * kk
                                 : (((2 * wave + (l31 >> 4)) * CF_IW + (l31 & 15)) * CF_PSF + 16 * kk) * 4;
         const int bbase = SPLIT ? l31 * CF_WROW * 4 + 16 * kk : (l31 * CF_WROW + 16 * kk) * 4;
-        const float bv = a.bias != nullptr ? a.bias[co] : 0.f;
+        // (bias is in ORIGINAL channel order: packed cout (phase, channel c) of a shuffled layer = original c * 4 + phase)
+        const float bv = a.bias != nullptr ? a.bias[a.shuffle ? co * 4 + ph : co] : 0.f;
         float st_shift = 0.f, st_s1 = 0.f, st_s2 = 0.f;     // running statistics of this lane's values, shifted sums
         int st_n = 0;
-        const __amdgpu_buffer_rsrc_t ry = cf_rsrc(a.y, tbytes), rr = cf_rsrc(a.res != nullptr ? a.res : a.y, tbytes);
+        const __amdgpu_buffer_rsrc_t ry = cf_rsrc(a.y, a.shuffle ? 4u * tbytes : tbytes), rr = cf_rsrc(a.res != nullptr ? a.res : a.y, tbytes);
         f32x16 acc;
 #if CF_CHAINS == 2
         f32x16 acc2;                                          // second accumulation chain (odd K steps), folded into acc before the epilogue
@@ -338,7 +344,10 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             CFT(4 + 6 * j);
             int n, ty, tx;
             tile_coords(stream + (j >> 1) * a.streams, n, ty, tx);
-            const unsigned obase = (unsigned)((((n * a.H + ty * CF_TH + 2 * wave) * a.W + tx * CF_TW) * 64 + co) * 4);
+            // (shuffled store: pixel (y, x) of phase (i, j) lands on (2 y + i, 2 x + j) of the [N][2H][2W][64] tensor)
+            const unsigned obase = a.shuffle ? (unsigned)((((n * 2 * a.H + 2 * (ty * CF_TH + 2 * wave) + (ph >> 1)) * 2 * a.W + 2 * tx * CF_TW + (ph & 1)) * 64 + co) * 4)
+                                             : (unsigned)((((n * a.H + ty * CF_TH + 2 * wave) * a.W + tx * CF_TW) * 64 + co) * 4);
+            const int orow = a.shuffle ? 4 * a.W * 256 : a.W * 256, ocol = a.shuffle ? 512 : 256;       // bytes per tile row / column of the store
             if (q == 0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = bv;
@@ -481,7 +490,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
                 for (int i = 0; i < 16; ++i) {
                     const int p = mfma_row(i, lane);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[i]), ry,
-                                                          obase + (unsigned)(((p >> 4) * a.W + (p & 15)) * 256), 0, 0);
+                                                          obase + (unsigned)((p >> 4) * orow + (p & 15) * ocol), 0, 0);
                 }
             }
 #ifdef CF_ABLATE_EPI
@@ -561,7 +570,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
 static int cf_streams(const SisrConvDesc* d) {
     const int total = d->N * (d->H / CF_TH) * (d->W / CF_TW);
     const int cus = sisr_cu_slots();
-    const int slots = std::max(1, cus / 2);     // two workgroups (the cout halves) per pixel-tile stream
+    const int slots = std::max(1, cus / (d->Cout == 256 ? 8 : 2));     // one workgroup per block of 32 couts and pixel-tile stream
     const int rounds = (total + slots - 1) / slots;
     return (total + rounds - 1) / rounds;       // equal shares
 }
@@ -572,13 +581,19 @@ extern "C" int sisr_conv2d_trunk_f32_eligible(const SisrConvDesc* d) {
     if (!d || (sw && sw[0] == '0')) return 0;
     const char* sw2 = getenv("SISR_TRUNK_F32CONV");
     if (sw2 && sw2[0] == '0') return 0;
-    if (d->Cin != 64 || d->Cout != 64 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
-    if (d->x_mode != SISR_X_NHWC || d->y_mode != SISR_Y_NHWC || d->x_bf16 || d->y_bf16 || d->res_bf16) return 0;
+    if (d->Cin != 64 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
+    // Cout = 64 (trunk), or 256 stored through PixelShuffle(2) -- the upscale conv, forward role without statistics
+    const char* swu = getenv("SISR_TRUNK_UP");                 // A/B switch for the upscale conv alone
+    const bool up = !(swu && swu[0] == '0') && d->Cout == 256 && d->y_mode == SISR_Y_NHWC_SHUFFLE2 && d->plan.CoutPad == 256 && !d->stat_part &&
+                    !d->res && !d->bnb_part && !d->fin_stat &&
+                    (d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT);
+    if (!up && (d->Cout != 64 || d->y_mode != SISR_Y_NHWC || d->plan.CoutPad != 64)) return 0;
+    if (d->x_mode != SISR_X_NHWC || d->x_bf16 || d->y_bf16 || d->res_bf16) return 0;
     if (d->Ho != d->H || d->Wo != d->W || (d->H % CF_TH) || (d->W % CF_TW)) return 0;
-    if (d->y_sy != 1 || d->y_sx != 1 || d->y_oy || d->y_ox || d->y_H != d->Ho || d->y_W != d->Wo) return 0;
+    if (!up && (d->y_sy != 1 || d->y_sx != 1 || d->y_oy || d->y_ox || d->y_H != d->Ho || d->y_W != d->Wo)) return 0;
     if (d->epi_act != SISR_EPI_NONE) return 0;
-    if (d->plan.CK != 32 || d->plan.PS != CF_PS || d->plan.KROWP != CF_KROWP || d->plan.CoutPad != 64 || d->plan.n_chunk != 2) return 0;
-    if ((int64_t)d->N * d->H * d->W * 256 >= (1ll << 31)) return 0;
+    if (d->plan.CK != 32 || d->plan.PS != CF_PS || d->plan.KROWP != CF_KROWP || d->plan.n_chunk != 2) return 0;
+    if ((int64_t)d->N * d->H * d->W * 256 * (up ? 4 : 1) >= (1ll << 31)) return 0;
     if (d->N * (d->H / CF_TH) * (d->W / CF_TW) >= 65536) return 0;
     const bool fwd_pro = d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT ||
                          (d->pro_mode == SISR_PRO_RES_AFFINE && d->x2 && d->x_out && ((d->pa && d->pd) || d->fin_stat));
@@ -608,7 +623,7 @@ static int launch_cf_t(const CTrunkF32Args& a, hipStream_t st) {
     constexpr int lds_bytes = 2 * CF_WCHUNK_BYTES + 2 * CF_HALO_BYTES + 4 * 32 * 3 * 4 + 128 * 4;
     static SisrLdsCap cap;
     if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&conv_trunk_f32_kernel<PRO, SPLIT>), lds_bytes)) return e;
-    hipLaunchKernelGGL((conv_trunk_f32_kernel<PRO, SPLIT>), dim3(2 * a.streams), dim3(CF_THREADS), lds_bytes, st, a);
+    hipLaunchKernelGGL((conv_trunk_f32_kernel<PRO, SPLIT>), dim3(a.streams << a.glog), dim3(CF_THREADS), lds_bytes, st, a);
     SISR_CHECK_LAUNCH();
     return 0;
 }
@@ -629,6 +644,7 @@ int sisr_conv2d_trunk_f32_launch(const SisrConvDesc* d, hipStream_t st) {
     a.N = d->N; a.H = d->H; a.W = d->W;
     a.tiles_x = d->W / CF_TW; a.per_img = (d->H / CF_TH) * a.tiles_x; a.total = d->N * a.per_img;
     a.streams = cf_streams(d);
+    a.glog = d->Cout == 256 ? 3 : 1; a.cout_pad = d->Cout == 256 ? 256 : 64; a.shuffle = d->y_mode == SISR_Y_NHWC_SHUFFLE2 ? 1 : 0;
     a.bnb_x = d->bnb_x; a.bnb_scale = d->bnb_scale; a.bnb_shift = d->bnb_shift; a.bnb_mean = d->bnb_mean; a.bnb_invstd = d->bnb_invstd;
     a.bnb_slope_p = d->bnb_slope_p; a.bnb_slope = d->bnb_slope; a.bnb_act = d->bnb_act; a.bnb_part = d->bnb_part;
     a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);

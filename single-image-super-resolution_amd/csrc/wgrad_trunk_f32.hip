@@ -69,6 +69,10 @@ struct WTrunkF32Args {
     int tiles_x, per_img, total;
     uint32_t m_tiles_x, m_per_img;
     int xpro;
+    // Cout = 256 with the gradient stored shuffled (the upscale conv, model_generator.py:43-48): four cout groups = the four
+    // PixelShuffle phases, workgroup b serves group b % 4 on tile stream b / 4; the gradient operand of group (i, j) is the
+    // strided view pixel (2 y + i, 2 x + j) of the [N][2H][2W][64] tensor.  A stream's four workgroups share one slab.
+    int glog, cout_pad, gshuffle;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wf_rsrc(const void* p, unsigned bytes) {
@@ -117,7 +121,9 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         tx = rem - ty * a.tiles_x;
         return (unsigned)(((n * a.H + ty * WF_TH) * a.W + tx * WF_TW) * 256);
     };
-    float* sl = a.slab + (int64_t)blockIdx.x * a.slab_stride;
+    const int cg = blockIdx.x & ((1 << a.glog) - 1);                    // cout group (shuffle phase) of this workgroup
+    const int t_first = blockIdx.x >> a.glog, t_step = gridDim.x >> a.glog;
+    float* sl = a.slab + (int64_t)t_first * a.slab_stride;
     constexpr int XB = SPLIT ? WS_XBYTES : WF_XBYTES, BUF = SPLIT ? WS_XBYTES + WS_DBYTES : WF_XBYTES + WF_DBYTES, PB = SPLIT ? WS_PB : WF_PB;
     // (accounting marks of thread 0, a consumer: 4 = role state ready, 5 = first barrier passed, 6 = tile loop done, 7 = end)
     if (!consumer) {
@@ -132,7 +138,8 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             ka[j] = aff ? a.pa[quad * 4 + j] : 1.f; kd[j] = aff ? a.pd[quad * 4 + j] : 0.f;
-            qa[j] = a.qa[quad * 4 + j]; qb[j] = a.qb[quad * 4 + j]; qd[j] = a.qd[quad * 4 + j];
+            qa[j] = GPRO != SISR_PRO_ACT_BWD ? a.qa[quad * 4 + j] : 0.f; qb[j] = GPRO != SISR_PRO_ACT_BWD ? a.qb[quad * 4 + j] : 0.f;
+            qd[j] = GPRO != SISR_PRO_ACT_BWD ? a.qd[quad * 4 + j] : 0.f;
             qs[j] = GPRO == SISR_PRO_BNACT_BWD ? a.qs[quad * 4 + j] : 0.f;
             qt[j] = GPRO == SISR_PRO_BNACT_BWD ? a.qt[quad * 4 + j] : 0.f;
         }
@@ -151,7 +158,12 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
             xflags |= f << (4 * k);
         }
         const bool last_beyond = m0 + 16 * (WF_XITEMS - 1) >= WF_NPIX;
-        const int grel0 = ((m0 >> 4) * a.W + (m0 & 15)) * 256 + quad * 16;   // tile pixel m0 + 16 k: one row further down per item
+        // tile pixel m0 + 16 k: one row further down per item; a shuffled gradient is read through the strided view of this
+        // workgroup's phase (pixel pitch 2, row pitch 2 * 2W)
+        const int gsc = a.gshuffle ? 2 : 1, gW = gsc * a.W;
+        const int grel0 = ((m0 >> 4) * gsc * gW + (m0 & 15) * gsc) * 256 + quad * 16;
+        const int gstep = gsc * gW * 256;
+        const unsigned gbytes = (unsigned)(gsc * gsc) * tbytes;
         const int xlds0 = m0 * PB + quad * (SPLIT ? 8 : 16), glds0 = XB + m0 * PB + quad * (SPLIT ? 8 : 16);
 
         // two staging register sets: the loads of tile T + 2 are in flight while tile T + 1 is transformed and written to LDS
@@ -161,9 +173,11 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         struct Stage { f32x4 sx[WF_XITEMS], s1[4], s2[4]; unsigned okm; };
         Stage stA, stB;
         auto issue = [&](int T, Stage& st) {
-            const __amdgpu_buffer_rsrc_t rx = wf_rsrc(a.x1, tbytes), r1 = wf_rsrc(a.g1, tbytes), r2 = wf_rsrc(a.g2, tbytes);
+            const __amdgpu_buffer_rsrc_t rx = wf_rsrc(a.x1, tbytes), r1 = wf_rsrc(a.g1, gbytes), r2 = wf_rsrc(a.g2, gbytes);
             int ty, tx;
             const unsigned origin = tile_origin(T, ty, tx);
+            const int n_img = fdiv(T, a.m_per_img);
+            const unsigned gorigin = a.gshuffle ? (unsigned)(((n_img * 2 * a.H + 2 * ty * WF_TH + (cg >> 1)) * gW + 2 * tx * WF_TW + (cg & 1)) * 256) : origin;
             const bool live = T < a.total;
             // every tile has an edge pattern; 15 marks "always outside" items (beyond the halo), which any non-zero mask hits
             const unsigned e = (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u);
@@ -177,7 +191,7 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const unsigned voff = live ? origin + (unsigned)(grel0 + k * a.W * 256) : 0x80000000u;
+                const unsigned voff = live ? gorigin + (unsigned)(grel0 + k * gstep) : 0x80000000u;
                 st.s1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0));
                 st.s2[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0));
             }
@@ -204,7 +218,8 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
                     float g = st.s1[k][j];
                     const float bx = st.s2[k][j];
                     if (GPRO == SISR_PRO_BNACT_BWD) g = qs[j] * bx + qt[j] > 0.f ? g : gslope * g;
-                    o[j] = qa[j] * g + qb[j] * bx + qd[j];
+                    if (GPRO == SISR_PRO_ACT_BWD) o[j] = bx > 0.f ? g : gslope * g;          // act'(pre-activation) * gradient
+                    else o[j] = qa[j] * g + qb[j] * bx + qd[j];
                 }
                 bsum += o;
                 if constexpr (SPLIT) wf_store_split(img + glds0 + k * 16 * PB, o);
@@ -212,24 +227,24 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
             }
         };
 
-        int T = blockIdx.x;
+        int T = t_first;
         issue(T, stA);
-        issue(T + gridDim.x, stB);
+        issue(T + t_step, stB);
         if (T < a.total) commit(stA, 0);
         __syncthreads();
         WFA_DECL;
         // unrolled by two: each staging set has a fixed name in each half (stB holds tile T + grid in the first)
         int cur = 0;
         while (T < a.total) {
-            issue(T + 2 * gridDim.x, stA);
-            if (T + (int)gridDim.x < a.total) commit(stB, cur ^ 1);
+            issue(T + 2 * t_step, stA);
+            if (T + t_step < a.total) commit(stB, cur ^ 1);
             WFA_SYNC();           // the next tile's images are complete; the consumers have finished reading this one
-            T += gridDim.x; cur ^= 1;
+            T += t_step; cur ^= 1;
             if (T >= a.total) break;
-            issue(T + 2 * gridDim.x, stB);
-            if (T + (int)gridDim.x < a.total) commit(stA, cur ^ 1);
+            issue(T + 2 * t_step, stB);
+            if (T + t_step < a.total) commit(stA, cur ^ 1);
             WFA_SYNC();
-            T += gridDim.x; cur ^= 1;
+            T += t_step; cur ^= 1;
         }
         if (wave == 4) WFA_STORE(2);
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the prefetch loads past the last tile
@@ -252,7 +267,7 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         // step); inside the group lane 4q + p addresses (pixel row q, channels 4p .. 4p + 3)
         const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
         const int rd_pix = (8 * (grp >> 1) + tq) * WS_PB + (16 * (grp & 1) + 4 * tp) * 2;
-        for (int T = blockIdx.x; T < a.total; T += gridDim.x, cur ^= 1) {
+        for (int T = t_first; T < a.total; T += t_step, cur ^= 1) {
             if constexpr (SPLIT) {
                 // halo rows R = 0 .. 5: the three column shifts of row R against the gradient rows R, R - 1, R - 2; small terms first
                 const unsigned char* xs = lds + cur * BUF + rd_pix + 64 * gq;
@@ -310,7 +325,7 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                sl[((gq * 3 + t / 3) * WF_KROWP + (t % 3) * WF_PS + mfma_row(i, lane)) * 64 + 32 * h + l31] = acc[t][i];
+                sl[((gq * 3 + t / 3) * WF_KROWP + (t % 3) * WF_PS + mfma_row(i, lane)) * a.cout_pad + 64 * cg + 32 * h + l31] = acc[t][i];
     }
     if (a.bias_slab != nullptr) {                       // ... and its bias row
         __syncthreads();
@@ -319,7 +334,7 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
             const int q4 = tid >> 2, j = tid & 3;
             float s = 0.f;
             for (int i = 0; i < 16; ++i) s += bs[(q4 + 16 * i) * 4 + j];                  // fixed order: deterministic
-            a.bias_slab[(int64_t)blockIdx.x * a.slab_stride + tid] = s;
+            a.bias_slab[(int64_t)t_first * a.slab_stride + 64 * cg + tid] = s;
         }
     }
     WFA_MARK(7);
@@ -329,8 +344,10 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
 static int wf_grid(const SisrWgradDesc* d) {
     const int total = d->N * (d->H / WF_TH) * (d->W / WF_TW);
     const int cus = sisr_cu_slots();
-    const int rounds = (total + cus - 1) / cus;
-    return (total + rounds - 1) / rounds;       // equal shares
+    const int G = d->Cout == 256 ? 4 : 1;       // cout groups: each tile stream is served by G workgroups
+    const int slots = std::max(1, cus / G);
+    const int rounds = (total + slots - 1) / slots;
+    return G * ((total + rounds - 1) / rounds);  // equal shares
 }
 
 extern "C" int sisr_wgrad_trunk_f32_eligible(const SisrWgradDesc* d) {
@@ -338,14 +355,20 @@ extern "C" int sisr_wgrad_trunk_f32_eligible(const SisrWgradDesc* d) {
     if (!d || (sw && sw[0] == '0')) return 0;
     const char* sw2 = getenv("SISR_TRUNK_WGRAD");
     if (sw2 && sw2[0] == '0') return 0;
-    if (d->Cin != 64 || d->Cout != 64 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
-    if (d->x_mode != SISR_X_NHWC || d->g_mode != SISR_X_NHWC || d->x_bf16 || d->g_bf16) return 0;
+    if (d->Cin != 64 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
+    // Cout = 64 (trunk: BatchNorm-backward gradient prologues), or 256 with the gradient stored shuffled and an
+    // activation-backward prologue -- the upscale conv
+    const char* swu = getenv("SISR_TRUNK_UP");                 // A/B switch for the upscale conv alone
+    const bool up = !(swu && swu[0] == '0') && d->Cout == 256 && d->g_mode == SISR_X_NHWC_UNSHUFFLE2 && d->CoutPad == 256 &&
+                    d->gpro_mode == SISR_PRO_ACT_BWD && (int64_t)d->N * d->H * d->W * 1024 < (1ll << 31);
+    if (!up && (d->Cout != 64 || d->g_mode != SISR_X_NHWC || d->CoutPad != 64)) return 0;
+    if (d->x_mode != SISR_X_NHWC || d->x_bf16 || d->g_bf16) return 0;
     if (d->Ho != d->H || d->Wo != d->W || (d->H % WF_TH) || (d->W % WF_TW)) return 0;
-    if (d->CK != 32 || d->PS != WF_PS || d->KROWP != WF_KROWP || d->CoutPad != 64 || d->n_chunk != 2) return 0;
+    if (d->CK != 32 || d->PS != WF_PS || d->KROWP != WF_KROWP || d->n_chunk != 2) return 0;
     if ((int64_t)d->N * d->H * d->W * 256 >= (1ll << 31)) return 0;
     if (d->N * (d->H / WF_TH) * (d->W / WF_TW) >= 65536) return 0;
     const bool xp = d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT;
-    const bool gp = d->gpro_mode == SISR_PRO_BNBWD || d->gpro_mode == SISR_PRO_BNACT_BWD;
+    const bool gp = up || d->gpro_mode == SISR_PRO_BNBWD || d->gpro_mode == SISR_PRO_BNACT_BWD;
     return xp && gp ? 1 : 0;
 }
 
@@ -357,7 +380,7 @@ int sisr_wgrad_toimage_slabs(const SisrWgradDesc* d);                         //
 
 extern "C" int sisr_wgrad_f32_slabs(const SisrWgradDesc* d) {
     if (!d) return SISR_E_BADARG;
-    if (sisr_wgrad_trunk_f32_eligible(d)) return wf_grid(d);
+    if (sisr_wgrad_trunk_f32_eligible(d)) return wf_grid(d) / (d->Cout == 256 ? 4 : 1);
     if (sisr_wgrad_thin_eligible(d)) return sisr_wgrad_thin_slabs(d);
     return sisr_wgrad_toimage_f32_eligible(d) ? sisr_wgrad_toimage_slabs(d) : d->n_slabs;
 }
@@ -380,7 +403,8 @@ static int launch_wf(const WTrunkF32Args& a, bool split, int grid, hipStream_t s
 int sisr_wgrad_trunk_f32_launch(const SisrWgradDesc* d, hipStream_t st) {
     if (operand_needs_x2(d->gpro_mode) && !d->g2) return SISR_E_BADARG;
     if (d->pro_mode == SISR_PRO_AFFINE_ACT && (!d->pa || !d->pd)) return SISR_E_BADARG;
-    if (!d->qa || !d->qb || !d->qd || (d->gpro_mode == SISR_PRO_BNACT_BWD && (!d->qs || !d->qt))) return SISR_E_BADARG;
+    if (d->gpro_mode != SISR_PRO_ACT_BWD && (!d->qa || !d->qb || !d->qd || (d->gpro_mode == SISR_PRO_BNACT_BWD && (!d->qs || !d->qt))))
+        return SISR_E_BADARG;
     WTrunkF32Args a;
     a.x1 = d->x1; a.g1 = d->g1; a.g2 = d->g2;
     a.pa = d->pa; a.pd = d->pd; a.xslope_p = d->pro_slope_p; a.xslope = d->pro_slope;
@@ -391,7 +415,9 @@ int sisr_wgrad_trunk_f32_launch(const SisrWgradDesc* d, hipStream_t st) {
     a.tiles_x = d->W / WF_TW; a.per_img = (d->H / WF_TH) * a.tiles_x; a.total = d->N * a.per_img;
     a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);
     a.xpro = d->pro_mode;
+    a.glog = d->Cout == 256 ? 2 : 0; a.cout_pad = d->Cout == 256 ? 256 : 64; a.gshuffle = d->g_mode == SISR_X_NHWC_UNSHUFFLE2 ? 1 : 0;
     const int grid = wf_grid(d);
+    if (d->gpro_mode == SISR_PRO_ACT_BWD) return launch_wf<SISR_PRO_ACT_BWD>(a, d->mfma_split != 0, grid, st);
     if (d->gpro_mode == SISR_PRO_BNBWD) return launch_wf<SISR_PRO_BNBWD>(a, d->mfma_split != 0, grid, st);
     return launch_wf<SISR_PRO_BNACT_BWD>(a, d->mfma_split != 0, grid, st);
 }

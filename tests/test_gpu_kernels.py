@@ -889,6 +889,90 @@ def test_trunk_kernel_upscale_conv_weight_gradient(E, L, shape, monkeypatch):
         E.set_precision('fp32')
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('pro', ['none', 'act', 'affine_act'])
+@pytest.mark.parametrize('shape', TRUNK_SHAPES_SHORT)
+def test_trunk_kernel_fp32_upscale_conv_with_pixel_shuffle_store(E, L, shape, pro, precision, monkeypatch):
+    """conv_trunk_f32.hip forward role with Cout = 256 stored through PixelShuffle(2) (the generator's upscale conv,
+    model_generator.py:43-48: eight blocks of 32 packed couts per pixel-tile stream) with fp32 tensors, exact and split
+    contraction, against the generic fp32 kernel and against F.pixel_shuffle(F.conv2d(...)) in double -- bias in original
+    channel order included"""
+    n, h, w = _walk(shape, monkeypatch)
+    x = _rand((n, 64, h, w), 281) * 2.0
+    wt = _rand((256, 64, 3, 3), 282, (1.0 / 576) ** 0.5 * 1.7)
+    b = _rand((256,), 283, 0.1)
+    sc, sh = _rand((64,), 284) * 0.5 + 1.0, _rand((64,), 285) * 0.3
+    slope = torch.tensor([0.25])
+    xin = x
+    if pro == 'act':
+        xin = F.leaky_relu(x, 0.25)
+    elif pro == 'affine_act':
+        xin = F.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None], 0.25)
+    y_ref = F.pixel_shuffle(F.conv2d(xin.double(), wt.double(), b.double(), padding=1), 2)
+    E.set_precision(precision)
+    try:
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 256, 3, 1, 1, shuffle2=True))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        assert not p.kinds[0]
+        xd = nhwc(x).cuda()
+        op = (E.Operand.plain(xd) if pro == 'none' else E.Operand.act(xd, slope.cuda()) if pro == 'act'
+              else E.Operand.affine_act(xd, sc.cuda(), sh.cuda(), slope.cuda()))
+        out = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_TRUNK_UP', sw)
+            out[sw] = E.conv_forward(p, op, bias=ref.bias)[0]
+        assert tuple(out['1'].shape) == (n, 2 * h, 2 * w, 64)
+        assert maxrel(nchw(out['1']), y_ref) < SPLIT_TOL[precision]
+        assert maxrel(out['1'], out['0']) < SPLIT_TOL[precision]
+        assert not torch.equal(out['1'], out['0'])                     # (two kernels: different summation order at least)
+    finally:
+        E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('shape', TRUNK_SHAPES_SHORT)
+def test_trunk_kernel_fp32_upscale_conv_weight_gradient(E, L, shape, precision, monkeypatch):
+    """wgrad_trunk_f32.hip with Cout = 256 and the gradient stored shuffled (the upscale conv: four cout groups = the four
+    PixelShuffle phases, activation-backward prologue on the strided view of each phase), fp32 tensors, exact and split
+    contraction, against the generic fp32 kernel and against autograd through conv -> pixel_shuffle -> PReLU"""
+    n, h, w = _walk(shape, monkeypatch)
+    x = _rand((n, 64, h, w), 291) * 2.0
+    wt = _rand((256, 64, 3, 3), 292, (1.0 / 576) ** 0.5 * 1.7)
+    b = _rand((256,), 293, 0.1)
+    slope = torch.tensor([0.25])
+    wr, br = wt.clone().double().requires_grad_(True), b.clone().double().requires_grad_(True)
+    pre_ref = F.pixel_shuffle(F.conv2d(x.double(), wr, br, padding=1), 2)
+    pre = pre_ref.detach().float()                               # the stored pre-activation (fp32 NHWC in the engine)
+    g = _rand((n, 64, 2 * h, 2 * w), 294)                        # gradient arriving at the PReLU output
+    gpre = torch.where(pre > 0, g, 0.25 * g)
+    pre_ref.backward(gpre.double())
+    E.set_precision(precision)
+    try:
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(64, 256, 3, 1, 1, shuffle2=True))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        assert not p.kinds[2]
+        x_op = E.Operand.plain(nhwc(x).cuda())
+        gd, pd_ = nhwc(g).cuda(), nhwc(pre).cuda()
+        dy_op = E.Operand(gd, (n, h, w, 256), pro=L.PRO_ACT_BWD, mode=L.X_UNSHUFFLE2, x2=pd_, slope=slope.cuda())
+        red = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_TRUNK_UP', sw)
+            red[sw] = E.conv_wgrad(p, x_op, dy_op)
+        def unpacked(r):
+            wg = E.WeightGradBatch()
+            wg.add(p, r)
+            return wg.run()[id(ref)]
+        (gw, gb), (gw0, gb0) = unpacked(red['1']), unpacked(red['0'])      # (the packed rows have padding the trunk kernel never writes)
+        assert maxrel(gw, gw0) < 2 * SPLIT_TOL[precision] and maxrel(gb, gb0) < 2 * SPLIT_TOL[precision]
+        assert not torch.equal(gw, gw0)
+        assert maxrel(gw, wr.grad) < 1e-4 and maxrel(gb, br.grad) < 1e-4
+        monkeypatch.setenv('SISR_TRUNK_UP', '1')
+        gw2, gb2 = unpacked(E.conv_wgrad(p, x_op, dy_op))
+        assert torch.equal(gw2, gw) and torch.equal(gb2, gb)
+    finally:
+        E.set_precision('fp32')
+
+
 @pytest.mark.parametrize('role', ['first_conv', 'end_dgrad'])
 @pytest.mark.parametrize('shape', [(2, 16, 32), (3, 48, 48), (1, 96, 96), (3, 48, 48, 4), (16, 96, 96), (4, 192, 192)])
 def test_thin_kernel_over_a_3_channel_image(E, L, shape, role, monkeypatch):
