@@ -93,6 +93,10 @@ struct CTrunkF32Args {
     // blocks of 32 packed couts per pixel-tile stream (glog = 3) instead of two; packed cout 64 (2 i + j) + c is channel c of
     // output pixel (2 y + i, 2 x + j)
     int glog, cout_pad, shuffle;
+    // data gradient of that conv (Cin = 256 read through the un-shuffling view of the [N][2H][2W][64] gradient): one launch per
+    // PixelShuffle phase -- the operand is the strided view pixel (2 y + i, 2 x + j) (xsc = 2, xph = 2 i + j), the weights that
+    // phase's two 32-channel chunks, and launches 1 .. 3 add onto the output of the one before (res = y)
+    int xsc, xph;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t cf_rsrc(const void* p, unsigned bytes) {
@@ -125,7 +129,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
     const int l31 = lane & 31, kk = lane >> 5;
     const int hc = blockIdx.x & ((1 << a.glog) - 1), stream = blockIdx.x >> a.glog;   // block of 32 output channels, pixel-tile stream
     const unsigned tbytes = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * 256u;
-    constexpr bool TWO = PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD || PRO == SISR_PRO_RES_AFFINE;
+    constexpr bool TWO = PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD || PRO == SISR_PRO_RES_AFFINE || PRO == SISR_PRO_ACT_BWD;
     constexpr bool SUM = PRO == SISR_PRO_RES_AFFINE;          // skip-sum prologue: lrelu(x1) + (a x2 + d), stored back once
     auto tile_coords = [&](int T, int& n, int& ty, int& tx) {
         n = fdiv(T, a.m_per_img);
@@ -193,7 +197,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
         for (int k = 0; k < CF_ITEMS; ++k) {
             const int px = m0 + 32 * k;
             const int py = px / CF_IW, pxx = px - py * CF_IW;
-            rel[k] = ((py - 1) * a.W + (pxx - 1)) * 256 + quad * 16;
+            rel[k] = ((py - 1) * a.xsc * a.xsc * a.W + (pxx - 1) * a.xsc) * 256 + quad * 16;
             const unsigned f = px >= CF_NPIX ? 15u
                                : (py == 0 ? 1u : 0u) | (py == CF_IH - 1 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == CF_IW - 1 ? 8u : 0u);
             flags |= f << (4 * k);
@@ -209,10 +213,11 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
         Stage stA, stB;
         auto issue = [&](int j, Stage& st) {
             const int T = stream + (j >> 1) * a.streams, q = j & 1;
-            const __amdgpu_buffer_rsrc_t r1 = cf_rsrc(a.x1, tbytes), r2 = cf_rsrc(TWO ? a.x2 : a.x1, tbytes);
+            const unsigned xbytes = (unsigned)(a.xsc * a.xsc) * tbytes;
+            const __amdgpu_buffer_rsrc_t r1 = cf_rsrc(a.x1, xbytes), r2 = cf_rsrc(TWO ? a.x2 : a.x1, xbytes);
             int n, ty, tx;
             tile_coords(T, n, ty, tx);
-            const unsigned origin = (unsigned)(((n * a.H + ty * CF_TH) * a.W + tx * CF_TW) * 256 + q * 128);
+            const unsigned origin = (unsigned)(((n * a.xsc * a.H + a.xsc * ty * CF_TH + (a.xph >> 1)) * a.xsc * a.W + a.xsc * tx * CF_TW + (a.xph & 1)) * 256 + q * 128);
             // edge pattern of the tile; 15 = every item outside (stage past the end)
             const unsigned e = j < n_stages ? (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u)
                                             : 16u;
@@ -244,6 +249,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
                     if (PRO == SISR_PRO_ACT) return lrelu(v, slope);
                     if (PRO == SISR_PRO_AFFINE_ACT) return lrelu(qa[c] * v + qd[c], slope);
                     if (SUM) return lrelu(v, slope) + (qa[c] * st.s2[k][c] + qd[c]);      // as sisr_eltwise_res_affine
+                    if (PRO == SISR_PRO_ACT_BWD) return st.s2[k][c] > 0.f ? v : slope * v;    // act'(pre-activation) * gradient
                     const float bx = st.s2[k][c];
                     float g = v;
                     if (PRO == SISR_PRO_BNACT_BWD) g = qs[c] * bx + qt[c] > 0.f ? v : slope * v;
@@ -276,9 +282,10 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = q * 32 + quad * 4 + j;
-                ka[q][j] = fin ? kfin[c] : (PRO == SISR_PRO_AFFINE_ACT || TWO) ? a.pa[c] : 1.f;
-                kd[q][j] = fin ? kfin[64 + c] : (PRO == SISR_PRO_AFFINE_ACT || TWO) ? a.pd[c] : 0.f;
-                kb[q][j] = (TWO && !SUM) ? a.pb[c] : 0.f;
+                constexpr bool AFF = PRO == SISR_PRO_AFFINE_ACT || (TWO && PRO != SISR_PRO_ACT_BWD);    // prologues with a / d constants
+                ka[q][j] = fin ? kfin[c] : AFF ? a.pa[c] : 1.f;
+                kd[q][j] = fin ? kfin[64 + c] : AFF ? a.pd[c] : 0.f;
+                kb[q][j] = (TWO && !SUM && PRO != SISR_PRO_ACT_BWD) ? a.pb[c] : 0.f;
                 ks[q][j] = PRO == SISR_PRO_BNACT_BWD ? a.ps[c] : 0.f;
                 kt[q][j] = PRO == SISR_PRO_BNACT_BWD ? a.pt[c] : 0.f;
             }
@@ -581,9 +588,18 @@ extern "C" int sisr_conv2d_trunk_f32_eligible(const SisrConvDesc* d) {
     if (!d || (sw && sw[0] == '0')) return 0;
     const char* sw2 = getenv("SISR_TRUNK_F32CONV");
     if (sw2 && sw2[0] == '0') return 0;
+    const char* swu = getenv("SISR_TRUNK_UP");                 // A/B switch for the upscale conv alone
+    // the upscale conv's data gradient: 256 -> 64 over the un-shuffling view of the gradient, activation-backward prologue: four
+    // launches of the data-gradient role, one per PixelShuffle phase (see CTrunkF32Args.xsc)
+    if (!(swu && swu[0] == '0') && d->Cin == 256 && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_y == 1 && d->pad_x == 1 &&
+        d->x_mode == SISR_X_NHWC_UNSHUFFLE2 && d->pro_mode == SISR_PRO_ACT_BWD && d->x2 && d->y_mode == SISR_Y_NHWC && !d->x_bf16 && !d->y_bf16 &&
+        !d->res_bf16 && d->Ho == d->H && d->Wo == d->W && !(d->H % CF_TH) && !(d->W % CF_TW) && d->y_sy == 1 && d->y_sx == 1 && !d->y_oy && !d->y_ox &&
+        d->y_H == d->Ho && d->y_W == d->Wo && d->epi_act == SISR_EPI_NONE && d->plan.CK == 32 && d->plan.PS == CF_PS && d->plan.KROWP == CF_KROWP &&
+        d->plan.CoutPad == 64 && d->plan.n_chunk == 8 && (int64_t)d->N * d->H * d->W * 1024 < (1ll << 31) &&
+        d->N * (d->H / CF_TH) * (d->W / CF_TW) < 65536 && !d->stat_part && !d->bias && !d->bnb_part && !d->fin_stat)
+        return 2;
     if (d->Cin != 64 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_y != 1 || d->pad_x != 1) return 0;
     // Cout = 64 (trunk), or 256 stored through PixelShuffle(2) -- the upscale conv, forward role without statistics
-    const char* swu = getenv("SISR_TRUNK_UP");                 // A/B switch for the upscale conv alone
     const bool up = !(swu && swu[0] == '0') && d->Cout == 256 && d->y_mode == SISR_Y_NHWC_SHUFFLE2 && d->plan.CoutPad == 256 && !d->stat_part &&
                     !d->res && !d->bnb_part && !d->fin_stat &&
                     (d->pro_mode == SISR_PRO_NONE || d->pro_mode == SISR_PRO_ACT || d->pro_mode == SISR_PRO_AFFINE_ACT);
@@ -635,7 +651,7 @@ static int launch_cf(const CTrunkF32Args& a, bool split, hipStream_t st) {
 // called by sisr_conv2d_f32 for eligible descriptors
 int sisr_conv2d_trunk_f32_launch(const SisrConvDesc* d, hipStream_t st) {
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
-    CTrunkF32Args a;
+    CTrunkF32Args a{};
     a.fin.stat = d->fin_stat; a.fin.cnt = d->fin_cnt; a.fin.gamma = d->fin_gamma; a.fin.beta = d->fin_beta;
     a.fin.rm = d->fin_rm; a.fin.rv = d->fin_rv; a.fin.k = d->fin_k; a.fin.rows = d->fin_rows; a.fin.momentum = d->fin_momentum; a.fin.eps = d->fin_eps;
     a.x1 = d->x1; a.x2 = d->x2; a.x_out = d->x_out; a.pa = d->pa; a.pb = d->pb; a.pd = d->pd; a.ps = d->ps; a.pt = d->pt;
@@ -648,6 +664,18 @@ int sisr_conv2d_trunk_f32_launch(const SisrConvDesc* d, hipStream_t st) {
     a.bnb_x = d->bnb_x; a.bnb_scale = d->bnb_scale; a.bnb_shift = d->bnb_shift; a.bnb_mean = d->bnb_mean; a.bnb_invstd = d->bnb_invstd;
     a.bnb_slope_p = d->bnb_slope_p; a.bnb_slope = d->bnb_slope; a.bnb_act = d->bnb_act; a.bnb_part = d->bnb_part;
     a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);
+    a.xsc = 1; a.xph = 0;
+    if (d->Cin == 256) {
+        // [8 chunks][3 filter rows][64 couts][KROWP]: phase ph owns chunks 2 ph, 2 ph + 1
+        a.xsc = 2;
+        for (int ph = 0; ph < 4; ++ph) {
+            a.xph = ph;
+            a.wpk = d->wpk + (size_t)ph * 2 * 3 * 64 * CF_KROWP;
+            a.res = ph == 0 ? d->res : d->y;
+            if (int e = launch_cf<SISR_PRO_ACT_BWD>(a, d->mfma_split != 0, st)) return e;
+        }
+        return 0;
+    }
     switch (d->pro_mode) {
         case SISR_PRO_NONE: return launch_cf<SISR_PRO_NONE>(a, d->mfma_split != 0, st);
         case SISR_PRO_ACT: return launch_cf<SISR_PRO_ACT>(a, d->mfma_split != 0, st);

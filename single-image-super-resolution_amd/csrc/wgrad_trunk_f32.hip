@@ -405,7 +405,7 @@ int sisr_wgrad_trunk_f32_launch(const SisrWgradDesc* d, hipStream_t st) {
     if (d->pro_mode == SISR_PRO_AFFINE_ACT && (!d->pa || !d->pd)) return SISR_E_BADARG;
     if (d->gpro_mode != SISR_PRO_ACT_BWD && (!d->qa || !d->qb || !d->qd || (d->gpro_mode == SISR_PRO_BNACT_BWD && (!d->qs || !d->qt))))
         return SISR_E_BADARG;
-    WTrunkF32Args a;
+    WTrunkF32Args a{};
     a.x1 = d->x1; a.g1 = d->g1; a.g2 = d->g2;
     a.pa = d->pa; a.pd = d->pd; a.xslope_p = d->pro_slope_p; a.xslope = d->pro_slope;
     a.qa = d->qa; a.qb = d->qb; a.qd = d->qd; a.qs = d->qs; a.qt = d->qt;

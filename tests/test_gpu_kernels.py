@@ -973,6 +973,44 @@ def test_trunk_kernel_fp32_upscale_conv_weight_gradient(E, L, shape, precision, 
         E.set_precision('fp32')
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('res', [False, True])
+@pytest.mark.parametrize('shape', TRUNK_SHAPES_SHORT)
+def test_trunk_kernel_fp32_upscale_conv_data_gradient(E, L, shape, res, precision, monkeypatch):
+    """conv_trunk_f32.hip, data gradient of the upscale conv (256 -> 64 over the un-shuffling view of the [N][2H][2W][64]
+    gradient, activation-backward prologue): four launches of the data-gradient role, one per PixelShuffle phase, each adding
+    onto the one before -- against the generic fp32 kernel and against autograd through conv -> pixel_shuffle -> PReLU"""
+    n, h, w = _walk(shape, monkeypatch)
+    x = (_rand((n, 64, h, w), 301) * 2.0).double().requires_grad_(True)
+    wt = _rand((256, 64, 3, 3), 302, (1.0 / 576) ** 0.5 * 1.7)
+    skip = _rand((n, 64, h, w), 303)
+    slope = torch.tensor([0.25])
+    pre_ref = F.pixel_shuffle(F.conv2d(x, wt.double(), None, padding=1), 2)
+    pre = pre_ref.detach().float()
+    g = _rand((n, 64, 2 * h, 2 * w), 304)
+    pre_ref.backward(torch.where(pre > 0, g, 0.25 * g).double())
+    want = x.grad + (skip.double() if res else 0.0)
+    E.set_precision(precision)
+    try:
+        ref = FakeConv(wt.cuda(), None, E.ConvGeom(64, 256, 3, 1, 1, shuffle2=True))
+        p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+        gd, pd_ = nhwc(g).cuda(), nhwc(pre).cuda()
+        dy_op = E.Operand(gd, (n, h, w, 256), pro=L.PRO_ACT_BWD, mode=L.X_UNSHUFFLE2, x2=pd_, slope=slope.cuda())
+        rd = nhwc(skip).cuda() if res else None
+        out = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_TRUNK_UP', sw)
+            out[sw] = E.conv_dgrad(p, dy_op, res=rd)
+        assert tuple(out['1'].shape) == (n, h, w, 64)
+        assert maxrel(nchw(out['1']), want) < 2 * SPLIT_TOL[precision]
+        assert maxrel(out['1'], out['0']) < 2 * SPLIT_TOL[precision]
+        assert not torch.equal(out['1'], out['0'])
+        if res:
+            assert torch.equal(rd, nhwc(skip).cuda())                      # the residual itself is read, never written
+    finally:
+        E.set_precision('fp32')
+
+
 @pytest.mark.parametrize('role', ['first_conv', 'end_dgrad'])
 @pytest.mark.parametrize('shape', [(2, 16, 32), (3, 48, 48), (1, 96, 96), (3, 48, 48, 4), (16, 96, 96), (4, 192, 192)])
 def test_thin_kernel_over_a_3_channel_image(E, L, shape, role, monkeypatch):
