@@ -17,7 +17,7 @@ Two kinds of checks:
 import pytest
 import torch
 
-from conftest import PARITY_BUILDS
+from conftest import F32_TENSOR_BUILDS
 from gpu_helpers import pkg
 from helpers import grads_close, oracle_fwd_bwd, rel_err
 
@@ -144,15 +144,24 @@ def _gpu_fwd_bwd(net, state, x, r):
     return out.detach().cpu(), xx.grad.cpu(), grads, {k: v.detach().cpu() for k, v in net.state_dict().items()}
 
 
-def _oracle_compare(net, cfg, state, x, r):
-    """one training-mode forward+backward of `net` (GPU, fp32 parity build) against the CPU oracle on the same state:
-    output, input gradient, EVERY parameter gradient tensor by tensor, advanced buffers -- all at 1e-3"""
+# The split build ('bf16x3': 2^-17 operands in the trunk contractions) is ~6x noisier than fp32 arithmetic in the FORWARD pass
+# (3e-5 against 5e-6 on the output of the 34 layers -- both far inside 1e-3), and every bit of forward noise flips proportionally
+# more activation masks: its GRADIENTS are held to wider, measured bounds (tools/parity_diag.py with SISR_PRECISION=bf16x3, B16 /
+# LR 96: nearly linear activations <= 2e-3 on the worst tensor; the reference's activations: input gradient 2.3e-2 max / 4e-3 RMS
+# against fp64 where the fp32 oracle itself is 7e-3 / 8e-4).  That is why it is NOT the parity build of record.
+GRAD_TOL = {'fp32': TOL, 'bf16x3': 3e-3}
+FLIP_BOUNDS = {'fp32': (5e-2, 5e-3, 1.5e-1, 3.0), 'bf16x3': (1e-1, 2e-2, 6e-1, 10.0)}   # max-norm, RMS, PReLU slope, x the oracle's mean RMS
+
+
+def _oracle_compare(net, cfg, state, x, r, build='fp32'):
+    """one training-mode forward+backward of `net` (GPU) against the CPU oracle on the same state: output, advanced buffers at
+    1e-3; input gradient and EVERY parameter gradient tensor by tensor at GRAD_TOL[build] (1e-3 for the fp32 parity build)"""
     out, gx, got, sd = _gpu_fwd_bwd(net, state, x, r)
     o_out, o_gx, o_grads, o_new = oracle_fwd_bwd(cfg, state, x, r)
     assert rel_err(out, o_out) < TOL, 'output'
-    assert rel_err(gx, o_gx) < TOL, 'input gradient'
+    assert rel_err(gx, o_gx) < GRAD_TOL[build], 'input gradient'
     assert set(got) == set(o_grads)
-    assert grads_close(got, o_grads, TOL) == []
+    assert grads_close(got, o_grads, GRAD_TOL[build]) == []
     for k, v in o_new.items():                                 # advanced u / v, running statistics, batch counters
         assert rel_err(sd[k].double(), v.double()) < TOL, k
     return out
@@ -160,7 +169,7 @@ def _oracle_compare(net, cfg, state, x, r):
 
 def _generator_case(lr, init, slopes=None):
     from oracle import init as oinit
-    mg = pkg('model_generator')                                 # (the build under test is set by the parity_build fixture)
+    mg = pkg('model_generator')                                 # (the build under test is set by the f32_build fixture)
     torch.manual_seed(0)
     net = mg.Generator(16, 64, 256, [2], use_sn=True).cuda().train()
     if init == 'default':
@@ -179,9 +188,9 @@ def _generator_case(lr, init, slopes=None):
     return net, {'kind': 'generator', 'list_scales': [2], 'n_suffix': 0}, state, x, r
 
 
-@pytest.mark.parametrize('parity_build', PARITY_BUILDS, indirect=True)
+@pytest.mark.parametrize('f32_build', F32_TENSOR_BUILDS, indirect=True)
 @pytest.mark.parametrize('lr,init', [(48, 'default'), (96, 'synthetic')])
-def test_full_size_generator_values_at_1e3_with_nearly_linear_activations(lr, init, parity_build):
+def test_full_size_generator_values_at_1e3_with_nearly_linear_activations(lr, init, f32_build):
     """model_generator.py:86-101 at config.py:79-80's sizes -- Generator(16, 64, 256, [2], use_sn=True), B16, LR 48
     (cfg2's generator: 288 tiles) and LR 96 (the headline workload: 1,152 tiles = 5 / 9 per workgroup, the schedule
     no small case reaches) -- against the CPU oracle, EVERY tensor at 1e-3 relative: output, input gradient, all 140
@@ -195,7 +204,7 @@ def test_full_size_generator_values_at_1e3_with_nearly_linear_activations(lr, in
     slopes near 1 the same kernels run the same schedule (general-slope code path, slope read from the device tensor)
     on a function that is smooth to within (1 - slope), so the stated tolerance is a meaningful per-tensor bound."""
     net, cfg, state, x, r = _generator_case(lr, init, slopes=(0.990, 0.999))
-    out = _oracle_compare(net, cfg, state, x, r)
+    out = _oracle_compare(net, cfg, state, x, r, build=f32_build)
     assert tuple(out.shape) == (B, 3, 2 * lr, 2 * lr)
 
 
@@ -205,7 +214,7 @@ def _errs(a, b):
     return float(d.abs().max() / b.abs().max()), float(d.pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
 
 
-def _flip_aware_compare(net, cfg, state, x, r, strict_keys=()):
+def _flip_aware_compare(net, cfg, state, x, r, strict_keys=(), build='fp32'):
     """Hard activations (the reference's own PReLU 0.25 / LeakyReLU 0.01) at full size.
     * FORWARD quantities -- output, advanced spectral-norm vectors, running statistics -- at 1e-3 against the fp32
       oracle (in fact ~1e-6).
@@ -236,25 +245,26 @@ def _flip_aware_compare(net, cfg, state, x, r, strict_keys=()):
         _, cr = _errs(o_grads[k], x_grads[k])
         g_rms.append(gr)
         c_rms.append(cr)
-        limit_max, limit_rms = (TOL, TOL) if any(k.startswith(p) for p in strict_keys) else (5e-2, 5e-3)
+        b_max, b_rms, b_slope, b_mean = FLIP_BOUNDS[build]
+        limit_max, limit_rms = (GRAD_TOL[build], GRAD_TOL[build]) if any(k.startswith(p) for p in strict_keys) else (b_max, b_rms)
         if k.endswith('.weight') and x_grads[k].numel() == 1:
-            limit_max = limit_rms = 1.5e-1                         # PReLU slope: ONE cancelling sum over 9-38 M products
+            limit_max = limit_rms = b_slope                        # PReLU slope: ONE cancelling sum over 9-38 M products
         if not (gm < limit_max and gr < limit_rms):
             bad.append((k, gm, gr))
     assert bad == []
     mg_, mc_ = sum(g_rms) / len(g_rms), sum(c_rms) / len(c_rms)
-    assert mg_ <= max(3.0 * mc_, TOL), (mg_, mc_)
+    assert mg_ <= max(FLIP_BOUNDS[build][3] * mc_, TOL), (mg_, mc_)
     return out
 
 
-@pytest.mark.parametrize('parity_build', PARITY_BUILDS, indirect=True)
+@pytest.mark.parametrize('f32_build', F32_TENSOR_BUILDS, indirect=True)
 @pytest.mark.parametrize('lr,init', [(48, 'default'), (96, 'synthetic')])
-def test_full_size_generator_with_the_references_activations(lr, init, parity_build):
+def test_full_size_generator_with_the_references_activations(lr, init, f32_build):
     """the same sizes with the reference's own activations (PReLU 0.25 from the default init / 0.1-0.4 synthetic):
     see _flip_aware_compare.  The last conv and the upscale conv sit behind one PReLU only; everything is held to the
     flip-aware bounds, the forward to 1e-3."""
     net, cfg, state, x, r = _generator_case(lr, init)
-    _flip_aware_compare(net, cfg, state, x, r, strict_keys=('end.',))
+    _flip_aware_compare(net, cfg, state, x, r, strict_keys=('end.',), build=f32_build)
 
 
 def test_full_size_discriminator_matches_the_oracle():

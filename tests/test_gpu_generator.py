@@ -3,7 +3,7 @@ from the reference modules, within BASELINE.json's 1e-3 relative fp32 tolerance.
 import pytest
 import torch
 
-from conftest import PARITY_BUILDS
+from conftest import F32_TENSOR_BUILDS
 from gpu_helpers import pkg
 from helpers import GEN_CASES, PROG_CASES, grads_close, load_case, rel_err
 
@@ -27,9 +27,9 @@ def build(cfg):
     return g
 
 
-@pytest.mark.parametrize('parity_build', PARITY_BUILDS, indirect=True)
+@pytest.mark.parametrize('f32_build', F32_TENSOR_BUILDS, indirect=True)
 @pytest.mark.parametrize('name', GEN_CASES + PROG_CASES)
-def test_generator_matches_reference_golden(name, parity_build):
+def test_generator_matches_reference_golden(name, f32_build):
     z, cfg, state, grads, after = load_case(name)
     net = build(cfg)
     net.load_state_dict(state, strict=True)
@@ -52,8 +52,8 @@ def test_generator_matches_reference_golden(name, parity_build):
         assert rel_err(net(x).cpu(), z['out_eval']) < TOL      # running statistics, no power iteration
 
 
-@pytest.mark.parametrize('parity_build', PARITY_BUILDS, indirect=True)
-def test_full_depth_generator_matches_reference_golden(parity_build):
+@pytest.mark.parametrize('f32_build', F32_TENSOR_BUILDS, indirect=True)
+def test_full_depth_generator_matches_reference_golden(f32_build):
     """16 residual blocks (34 stacked conv+BatchNorm layers, spectral norm on every conv; the benchmark's own
     architecture, config.py:79-80) at B2, LR 16: out / grad_x / sampled parameter gradients / advanced SN+BN state /
     second training forward against vectors captured from the imported reference module, 1e-3 relative fp32"""
@@ -71,7 +71,7 @@ def test_full_depth_generator_matches_reference_golden(parity_build):
     assert rel_err(out.detach().cpu(), z['out']) < TOL
     (out * torch.from_numpy(z['r']).cuda()).sum().backward()
     got, ref = sample({k: p.grad.detach().cpu() for k, p in net.named_parameters()})
-    if parity_build == 'fp32':
+    if f32_build == 'fp32':
         assert rel_err(x.grad.cpu(), z['grad_x']) < TOL
         assert grads_close(got, ref, TOL) == []
     else:
