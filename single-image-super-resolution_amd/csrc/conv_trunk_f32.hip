@@ -28,6 +28,9 @@ typedef unsigned cf_u32x4 __attribute__((ext_vector_type(4)));
 #include <algorithm>
 #include <cstdlib>
 
+#ifndef CF_XCD_PAIRS
+#define CF_XCD_PAIRS 1
+#endif
 #ifndef CF_CHAINS
 #define CF_CHAINS 1
 #endif
@@ -127,7 +130,16 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool consumer = wave < 4;
     const int l31 = lane & 31, kk = lane >> 5;
-    const int hc = blockIdx.x & ((1 << a.glog) - 1), stream = blockIdx.x >> a.glog;   // block of 32 output channels, pixel-tile stream
+    // block of 32 output channels, pixel-tile stream.  The workgroups of one stream stage the SAME halo tiles in the same order: they
+    // sit 8 apart in the grid, i.e. (workgroups being dealt round-robin over the 8 XCDs) on ONE XCD, so that the second reader of
+    // a tile finds it in that XCD's L2 instead of fetching it again over the fabric
+#if CF_XCD_PAIRS
+    const bool xcd = (a.streams & 7) == 0;
+    const int hc = xcd ? (blockIdx.x >> 3) & ((1 << a.glog) - 1) : blockIdx.x & ((1 << a.glog) - 1);
+    const int stream = xcd ? (blockIdx.x & 7) | ((blockIdx.x >> (3 + a.glog)) << 3) : blockIdx.x >> a.glog;
+#else
+    const int hc = blockIdx.x & ((1 << a.glog) - 1), stream = blockIdx.x >> a.glog;
+#endif
     const unsigned tbytes = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * 256u;
     constexpr bool TWO = PRO == SISR_PRO_BNBWD || PRO == SISR_PRO_BNACT_BWD || PRO == SISR_PRO_RES_AFFINE || PRO == SISR_PRO_ACT_BWD;
     constexpr bool SUM = PRO == SISR_PRO_RES_AFFINE;          // skip-sum prologue: lrelu(x1) + (a x2 + d), stored back once
@@ -395,9 +407,15 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         ah[t][ks] = *reinterpret_cast<const bf16x8*>(pa + 32 * ks);
+#ifdef CF_ABLATE_BREADS        // timing-only (wrong results): the weight fragments are not read from LDS (what registers would give)
+                        al[t][ks] = *reinterpret_cast<const bf16x8*>(pa + 64 + 32 * ks);
+                        bh[t][ks] = al[t][ks]; bl[t][ks] = ah[t][ks];
+                        asm volatile("" :: "v"(pb));
+#else
                         bh[t][ks] = *reinterpret_cast<const bf16x8*>(pb + 32 * ks);
                         al[t][ks] = *reinterpret_cast<const bf16x8*>(pa + 64 + 32 * ks);
                         bl[t][ks] = *reinterpret_cast<const bf16x8*>(pb + 64 + 32 * ks);
+#endif
                     }
                 };
                 fetch_s(0);
