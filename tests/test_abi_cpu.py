@@ -112,6 +112,62 @@ def test_shape_specific_kernels_claim_exactly_their_descriptors(monkeypatch):
     assert lib.sisr_conv2d_toimage_f32_eligible(f3) == 0 and lib.sisr_wgrad_toimage_f32_eligible(g3) == 0
 
 
+def test_fp32_trunk_kernels_claim_the_upscale_conv_only_as_they_can_run_it(monkeypatch):
+    """Host-side dispatch rules of the fp32-tensor persistent kernels for the generator's upscale conv (model_generator.py:43-48):
+    forward (Cout 256 stored through PixelShuffle(2)) without the fusions that variant has no code for; data gradient (Cin 256
+    read through the un-shuffling view) only with the activation-backward prologue and both of its tensors; weight gradient only
+    with the shuffled gradient view + activation-backward prologue.  SisrConvDesc.mfma_split never changes who takes a descriptor."""
+    E, L = _pkg('engine'), _pkg('_lib')
+    lib = L.lib()
+    for v in ('SISR_TRUNK', 'SISR_TRUNK_UP', 'SISR_TRUNK_F32CONV', 'SISR_TRUNK_WGRAD', 'SISR_PERSIST_MAX_WG'):
+        monkeypatch.delenv(v, raising=False)
+    E.set_precision('fp32')
+    one = 1
+    f, d, g, kinds = E.ConvGeom(64, 256, 3, 1, 1, shuffle2=True).plans(16, 96, 96)
+    assert kinds == (False, False, False)
+    u = L.ConvDesc.from_buffer_copy(f)
+    u.x1 = u.wpk = u.y = one
+    assert u.y_mode == L.Y_SHUFFLE2 and lib.sisr_conv2d_trunk_f32_eligible(u) == 1
+    for split in (0, 1):
+        u.mfma_split = split
+        assert lib.sisr_conv2d_trunk_f32_eligible(u) == 1
+    for field in ('stat_part', 'res', 'bnb_part', 'fin_stat'):
+        v = L.ConvDesc.from_buffer_copy(u)
+        setattr(v, field, one)
+        assert lib.sisr_conv2d_trunk_f32_eligible(v) == 0, field
+    v = L.ConvDesc.from_buffer_copy(u)
+    v.y_mode = L.Y_NHWC
+    assert lib.sisr_conv2d_trunk_f32_eligible(v) == 0              # Cout 256 WITHOUT the shuffled store
+    v = L.ConvDesc.from_buffer_copy(u)
+    v.pro_mode = L.PRO_RES_AFFINE
+    v.x2 = v.x_out = v.pa = v.pd = one
+    assert lib.sisr_conv2d_trunk_f32_eligible(v) == 0
+    # ---- data gradient: 256 -> 64 over the un-shuffling view
+    dd = L.ConvDesc.from_buffer_copy(d)
+    assert (dd.Cin, dd.Cout) == (256, 64)
+    dd.x1 = dd.x2 = dd.wpk = dd.y = one
+    dd.x_mode, dd.pro_mode = L.X_UNSHUFFLE2, L.PRO_ACT_BWD
+    assert lib.sisr_conv2d_trunk_f32_eligible(dd) == 2
+    dd.res = one
+    assert lib.sisr_conv2d_trunk_f32_eligible(dd) == 2             # the skip gradient rides on the first phase's launch
+    for field, val in (('x2', None), ('pro_mode', L.PRO_NONE), ('x_mode', L.X_NHWC), ('bias', one), ('bnb_part', one), ('stat_part', one)):
+        v = L.ConvDesc.from_buffer_copy(dd)
+        setattr(v, field, val)
+        assert lib.sisr_conv2d_trunk_f32_eligible(v) == 0, field
+    # ---- weight gradient: the gradient read through the strided view of each PixelShuffle phase
+    w = L.WgradDesc.from_buffer_copy(g)
+    w.x1 = w.g1 = w.g2 = w.slab = one
+    w.g_mode, w.gpro_mode = L.X_UNSHUFFLE2, L.PRO_ACT_BWD
+    assert lib.sisr_wgrad_trunk_f32_eligible(w) == 1 and lib.sisr_wgrad_f32_slabs(w) <= 64      # one slab per tile stream (4 workgroups)
+    for field, val in (('g_mode', L.X_NHWC), ('gpro_mode', L.PRO_BNBWD)):
+        v = L.WgradDesc.from_buffer_copy(w)
+        setattr(v, field, val)
+        assert lib.sisr_wgrad_trunk_f32_eligible(v) == 0, field
+    monkeypatch.setenv('SISR_TRUNK_UP', '0')
+    assert lib.sisr_conv2d_trunk_f32_eligible(u) == 0 and lib.sisr_conv2d_trunk_f32_eligible(dd) == 0
+    assert lib.sisr_wgrad_trunk_f32_eligible(w) == 0
+
+
 def test_trunk_kernels_claim_exactly_their_descriptors(monkeypatch):
     """Host-side dispatch rules of the persistent trunk kernels (pure host code): sisr_conv2d_trunk_eligible returns
     1 (forward role) / 2 (data-gradient role) only for 3x3 64 -> 64 bf16 NHWC descriptors on 8 x 16 tile grids, and for

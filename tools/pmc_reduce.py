@@ -45,7 +45,7 @@ for role in ('fwd', 'dgrad', 'wgrad'):
 json.dump(out, open(os.path.join(d, 'pmc_per_launch.json'), 'w'), indent=1)
 # the file bench.py reads its `traffic` from (profiles/r02_traffic.json)
 commit = os.environ.get('SISR_COMMIT', '?')
-fam = 'f32' if os.environ.get('SISR_PRECISION', 'bf16') == 'fp32' else 'bf16'
+fam = {'fp32': 'f32', 'bf16x3': 'split'}.get(os.environ.get('SISR_PRECISION', 'bf16'), 'bf16')
 json.dump({fam + '_' + role: {'traffic_bytes_per_launch': rec['traffic_bytes_per_launch'], 'kernel': rec.get('kernel'), 'commit': commit}
            for role, rec in out.items() if 'traffic_bytes_per_launch' in rec}, open(os.path.join(d, 'traffic.json'), 'w'), indent=1)
 for role, rec in out.items():
