@@ -1,19 +1,16 @@
 #!/bin/bash
-# Round-end evidence in one GPU call: full -m gpu suite, smoke, the default bench line, per-kernel stats of both builds
-# and the ordered kernel list of one bf16 step.  Everything lands under gpurun_out/$1/.
+# Round-end evidence in one GPU call: smoke, the default bench line, per-kernel stats + ordered kernel lists of the three builds,
+# PMC counters of the fp32 trunk kernels.  Everything lands under gpurun_out/$1/.  (The -m gpu suite is run by its own call.)
+# usage: bash tools/final_evidence.sh <name> <commit> [nobench]
 out=$GRAFT_REPO_ROOT/gpurun_out/${1:-final}
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > $out/test.log 2>&1; echo "pytest rc=$?" | tee $out/status.txt
-tail -2 $out/test.log
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $out/status.txt
-python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?" | tee -a $out/status.txt
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kb -- python3 $GRAFT_REPO_ROOT/bench.py --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline --configs none > $out/kb.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kf -- python3 $GRAFT_REPO_ROOT/bench.py --precision fp32 --steps 10 --warmup 3 --no-cpu-baseline --configs none > $out/kf.log 2>&1
-cd $GRAFT_REPO_ROOT
-cp $(find /tmp/kb -name "*kernel_stats.csv" | head -1) $out/bf16_kernel_stats.csv
-cp $(find /tmp/kf -name "*kernel_stats.csv" | head -1) $out/fp32_kernel_stats.csv
-python tools/trace_order.py $(find /tmp/kb -name "*kernel_trace.csv" | head -1) > $out/order_bf16.txt
-tail -1 $out/order_bf16.txt
-cut -c1-300 $out/bench.json
+if [ "${3:-}" != nobench ]; then
+    timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1 || { echo "smoke failed"; tail -3 $out/smoke.log; exit 1; }
+    tail -3 $out/smoke.log
+    /usr/bin/time -f "bench wall %e s" timeout -k 10 900 python bench.py > $out/bench.json 2> $out/bench.err || { echo "bench failed"; tail -3 $out/bench.err; exit 1; }
+    tail -1 $out/bench.err
+fi
+bash tools/evidence_stats.sh ${1:-final} || exit 1
+SISR_PRECISION=fp32 SISR_COMMIT=${2:-HEAD} timeout -k 10 600 bash tools/pmc_collect.sh gpurun_out/${1:-final}/pmc_fp32 > $out/pmc_fp32.log 2>&1
+tail -3 $out/pmc_fp32.log
