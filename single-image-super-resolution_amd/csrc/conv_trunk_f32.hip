@@ -27,6 +27,7 @@ typedef unsigned cf_u32x4 __attribute__((ext_vector_type(4)));
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef CF_XCD_PAIRS
 #define CF_XCD_PAIRS 1
@@ -204,24 +205,32 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
         const float slope = PRO != SISR_PRO_NONE ? (a.slope_p ? a.slope_p[0] : a.slope) : 1.f;
         f32x4 ka[2], kb[2], kd[2], ks[2], kt[2];
         int rel[CF_ITEMS];
-        unsigned flags = 0;                         // 4 bits per item: halo row 0 / last row / column 0 / last column; 15 = beyond
+        // 5 bits per item: halo row 0 / last row / column 0 / last column / beyond the 180 halo pixels.  A tile's edge pattern (the
+        // same 5 bits: image missing above / below / left / right, and 1) replicated over the items and ANDed with this is non-zero
+        // exactly for the items whose LDS slot must be zero (conv_trunk.hip's scheme).  The producers get about one instruction
+        // issued per MFMA of the consumer wave on their SIMD (profiles/r03_trace_trunk_f32_fwd.txt: 5.4 us of producer work per
+        // 4.7 us stage made the consumers wait 0.55 us at every second barrier), so their instruction count is what is tuned here.
+        unsigned flags = 0;
 #pragma unroll
         for (int k = 0; k < CF_ITEMS; ++k) {
             const int px = m0 + 32 * k;
             const int py = px / CF_IW, pxx = px - py * CF_IW;
             rel[k] = ((py - 1) * a.xsc * a.xsc * a.W + (pxx - 1) * a.xsc) * 256 + quad * 16;
-            const unsigned f = px >= CF_NPIX ? 15u
-                               : (py == 0 ? 1u : 0u) | (py == CF_IH - 1 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == CF_IW - 1 ? 8u : 0u);
-            flags |= f << (4 * k);
+            const unsigned f = (py == 0 ? 1u : 0u) | (py == CF_IH - 1 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == CF_IW - 1 ? 8u : 0u) |
+                               (px >= CF_NPIX ? 16u : 0u);
+            flags |= f << (5 * k);
         }
         const bool last_beyond = m0 + 32 * (CF_ITEMS - 1) >= CF_NPIX;
         const int ldso = SPLIT ? m0 * CF_PSF * 4 + quad * 8 : (m0 * CF_PSF + quad * 4) * 4;
+        const bool easy_slope = slope >= 0.f && slope <= 1.f;
 
         // two staging register sets: the loads of stage j + 2 fly while stage j + 1 is transformed and written to LDS (a
         // stage lasts ~4 us of MFMAs; a cold load round trip under a chip-wide load burst is not much shorter).  issue() is
-        // always executed -- past the last stage every offset is out of range, which costs an instruction and no traffic --
-        // so that the loop has no control flow around loads and the compiler's wait counts stay exact.
-        struct Stage { f32x4 s1[CF_ITEMS], s2[CF_ITEMS]; unsigned okm, origin; };
+        // always executed, so that the loop has no control flow around loads and the compiler's wait counts stay exact.  Every
+        // item is loaded from where it would sit in the tensor, inside the image or not (a buffer load past either end of the
+        // tensor returns zeros; one that lands on a neighbouring row's pixels returns values commit() replaces by zeros): no
+        // per-item address select.
+        struct Stage { f32x4 s1[CF_ITEMS], s2[CF_ITEMS]; unsigned bad, origin; bool edge; };
         Stage stA, stB;
         auto issue = [&](int j, Stage& st) {
             const int T = stream + (j >> 1) * a.streams, q = j & 1;
@@ -230,22 +239,22 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             int n, ty, tx;
             tile_coords(T, n, ty, tx);
             const unsigned origin = (unsigned)(((n * a.xsc * a.H + a.xsc * ty * CF_TH + (a.xph >> 1)) * a.xsc * a.W + a.xsc * tx * CF_TW + (a.xph & 1)) * 256 + q * 128);
-            // edge pattern of the tile; 15 = every item outside (stage past the end)
-            const unsigned e = j < n_stages ? (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u)
-                                            : 16u;
-            st.okm = 0;
+            const unsigned e = (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u);
+            st.edge = e != 0u;                                               // wave-uniform: this tile has items outside the image
+            st.bad = flags & ((e | 16u) * 0x02108421u);                      // (stages past the end are never committed)
             st.origin = origin;
 #pragma unroll
             for (int k = 0; k < CF_ITEMS; ++k) {
-                const unsigned f = (flags >> (4 * k)) & 15u;
-                const bool ok = f != 15u && (f & e) == 0u && e != 16u;
-                st.okm |= ok ? (1u << k) : 0u;
-                const unsigned voff = ok ? origin + (unsigned)rel[k] : 0x80000000u;
+                const unsigned voff = origin + (unsigned)rel[k];
                 st.s1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0));
                 if (TWO) st.s2[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0));
             }
         };
-        auto commit = [&](int j, const Stage& st) {
+        // EASY: 0 <= slope <= 1 (every slope this model family uses): leaky ReLU = max(v, slope v), no compare + select.
+        // EDGE: the tile has items outside the image (their LDS slots are zero AFTER the transform); an interior tile skips the selects.
+        auto commit_t = [&](auto easy_, auto edge_, int j, const Stage& st) {
+            constexpr int EASY = decltype(easy_)::value;
+            constexpr bool EDGE = decltype(edge_)::value;
             const int q = j & 1;
             float* img = reinterpret_cast<float*>(halo0 + (j & 1) * CF_HALO_BYTES + ldso);
             // (selects, not dynamically indexed arrays: those would live in scratch)
@@ -254,13 +263,13 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
 #pragma unroll
             for (int k = 0; k < CF_ITEMS; ++k) {
                 if (k == CF_ITEMS - 1 && last_beyond) break;
-                const bool ok = (st.okm >> k) & 1u;
+                const bool ok = !EDGE || ((st.bad >> (5 * k)) & 31u) == 0u;
                 auto value = [&](int c) {
                     const float v = st.s1[k][c];
                     if (PRO == SISR_PRO_NONE) return v;
-                    if (PRO == SISR_PRO_ACT) return lrelu(v, slope);
-                    if (PRO == SISR_PRO_AFFINE_ACT) return lrelu(qa[c] * v + qd[c], slope);
-                    if (SUM) return lrelu(v, slope) + (qa[c] * st.s2[k][c] + qd[c]);      // as sisr_eltwise_res_affine
+                    if (PRO == SISR_PRO_ACT) return lrelu_t<EASY>(v, slope);
+                    if (PRO == SISR_PRO_AFFINE_ACT) return lrelu_t<EASY>(qa[c] * v + qd[c], slope);
+                    if (SUM) return lrelu_t<EASY>(v, slope) + (qa[c] * st.s2[k][c] + qd[c]);      // as sisr_eltwise_res_affine
                     if (PRO == SISR_PRO_ACT_BWD) return st.s2[k][c] > 0.f ? v : slope * v;    // act'(pre-activation) * gradient
                     const float bx = st.s2[k][c];
                     float g = v;
@@ -282,8 +291,18 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
                 *reinterpret_cast<f32x4*>(img + k * 32 * CF_PSF) = ok ? osum : zero4;        // the halo is zero AFTER the transform
                 // skip-sum prologue: the tile's own 8 x 16 pixels (no halo flag) store the materialised sum, once per pixel
                 // and channel half -- by the workgroup of cout half 0 (its partner stages the same tiles)
-                if (SUM && hc == 0 && ((flags >> (4 * k)) & 15u) == 0u)
+                if (SUM && hc == 0 && ((flags >> (5 * k)) & 31u) == 0u)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cf_u32x4, osum), ro, st.origin + (unsigned)rel[k], 0, 0);
+            }
+        };
+        auto commit = [&](int j, const Stage& st) {
+            using T1 = std::integral_constant<int, 1>; using T0 = std::integral_constant<int, 0>;
+            // (prologues without a leaky ReLU have nothing that depends on EASY: one instantiation)
+            constexpr bool HAS_ACT = PRO == SISR_PRO_ACT || PRO == SISR_PRO_AFFINE_ACT || SUM;
+            if (!HAS_ACT || easy_slope) {
+                if (st.edge) commit_t(T1{}, std::true_type{}, j, st); else commit_t(T1{}, std::false_type{}, j, st);
+            } else {
+                if (st.edge) commit_t(T0{}, std::true_type{}, j, st); else commit_t(T0{}, std::false_type{}, j, st);
             }
         };
 

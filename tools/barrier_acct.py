@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import bench
 dev = torch.device('cuda', 0)
 if os.environ.get('ROLE') == 'wgrad_f32':
-    r = bench.kernel_rooflines(dev, 'fp32', iters=20, only=('wgrad',))[0]
+    r = bench.kernel_rooflines(dev, os.environ.get('SISR_PRECISION', 'fp32'), iters=20, only=('wgrad',))[0]
     print('fp32 wgrad + slab reduce launch %.2f us (HIP events)' % (r['launch_ms'] * 1e3))
     torch.cuda.synchronize()
     L = C.CDLL(os.environ['SISR_LIB'])
