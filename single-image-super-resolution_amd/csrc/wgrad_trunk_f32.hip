@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #define WF_TH 4
 #define WF_TW 16
@@ -170,45 +171,58 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         // (a tile lasts ~8 us of MFMAs; loading synchronously inside that window left the consumers waiting at 12 % of their
         // barriers' time for a late tile: tools/barrier_acct.py).  issue() is always executed -- past the last tile every offset
         // is out of range: an instruction, no traffic -- so that the loop has no control flow around loads.
-        struct Stage { f32x4 sx[WF_XITEMS], s1[4], s2[4]; unsigned okm; };
+        // (instruction count of the producers is what is tuned here -- they get about one instruction issued per MFMA of the consumer
+        // wave on their SIMD, and the consumers of the exact kernel waited 10 % of the tile loop for them: no per-item address
+        // selects (a buffer load past either end of the tensor returns zeros, one that lands on a neighbouring row's pixels
+        // returns values commit() replaces by zeros), the edge test as one AND with the tile's replicated edge pattern, leaky
+        // ReLU as max(v, slope v) for slopes in [0, 1], and interior tiles skip the zero selects)
+        struct Stage { f32x4 sx[WF_XITEMS], s1[4], s2[4]; unsigned bad; bool edge; };
         Stage stA, stB;
+        const bool easy_slope = xslope >= 0.f && xslope <= 1.f;
         auto issue = [&](int T, Stage& st) {
             const __amdgpu_buffer_rsrc_t rx = wf_rsrc(a.x1, tbytes), r1 = wf_rsrc(a.g1, gbytes), r2 = wf_rsrc(a.g2, gbytes);
             int ty, tx;
             const unsigned origin = tile_origin(T, ty, tx);
             const int n_img = fdiv(T, a.m_per_img);
             const unsigned gorigin = a.gshuffle ? (unsigned)(((n_img * 2 * a.H + 2 * ty * WF_TH + (cg >> 1)) * gW + 2 * tx * WF_TW + (cg & 1)) * 256) : origin;
-            const bool live = T < a.total;
-            // every tile has an edge pattern; 15 marks "always outside" items (beyond the halo), which any non-zero mask hits
+            // (tiles past the end are never committed; their offsets lie past the tensor or on its last rows: zeros / unused values)
             const unsigned e = (ty == 0 ? 1u : 0u) | (ty == tiles_y - 1 ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (tx == a.tiles_x - 1 ? 8u : 0u);
-            st.okm = 0;
+            st.edge = e != 0u;                                               // wave-uniform
+            st.bad = xflags & (e * 0x01111111u);                             // non-zero nibble k: item k lies outside the image
 #pragma unroll
-            for (int k = 0; k < WF_XITEMS; ++k) {
-                const unsigned f = (xflags >> (4 * k)) & 15u;
-                const bool ok = live && f != 15u && (f & e) == 0u;
-                st.okm |= ok ? (1u << k) : 0u;
-                st.sx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? origin + (unsigned)xrel[k] : 0x80000000u, 0, 0));
-            }
+            for (int k = 0; k < WF_XITEMS; ++k)
+                st.sx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, origin + (unsigned)xrel[k], 0, 0));
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const unsigned voff = live ? gorigin + (unsigned)(grel0 + k * gstep) : 0x80000000u;
+                const unsigned voff = gorigin + (unsigned)(grel0 + k * gstep);
                 st.s1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, 0, 0));
                 st.s2[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, voff, 0, 0));
             }
         };
-        auto commit = [&](const Stage& st, int b) {
-            unsigned char* img = lds + b * BUF;
+        auto commit_x = [&](auto easy_, auto edge_, const Stage& st, unsigned char* img) {
+            constexpr int EASY = decltype(easy_)::value;
+            constexpr bool EDGE = decltype(edge_)::value;
             // x: lrelu(a x + d) (a = 1, d = 0, slope = 1 degenerate to ACT / NONE), zero outside the image
 #pragma unroll
             for (int k = 0; k < WF_XITEMS; ++k) {
+                const bool ok = !EDGE || ((st.bad >> (4 * k)) & 15u) == 0u;
                 f32x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (st.okm >> k) & 1u ? lrelu(ka[j] * st.sx[k][j] + kd[j], xslope) : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const float v = lrelu_t<EASY>(ka[j] * st.sx[k][j] + kd[j], xslope);
+                    o[j] = ok ? v : 0.f;
+                }
                 if (k < WF_XITEMS - 1 || !last_beyond) {
                     if constexpr (SPLIT) wf_store_split(img + xlds0 + k * 16 * PB, o);
                     else *reinterpret_cast<f32x4*>(img + xlds0 + k * 16 * PB) = o;
                 }
             }
+        };
+        auto commit = [&](const Stage& st, int b) {
+            unsigned char* img = lds + b * BUF;
+            using T1 = std::integral_constant<int, 1>; using T0 = std::integral_constant<int, 0>;
+            if (easy_slope) { if (st.edge) commit_x(T1{}, std::true_type{}, st, img); else commit_x(T1{}, std::false_type{}, st, img); }
+            else { if (st.edge) commit_x(T0{}, std::true_type{}, st, img); else commit_x(T0{}, std::false_type{}, st, img); }
             // gradient: BatchNorm backward (through the activation for BNACT_BWD); the bias gradient is summed on the way
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
