@@ -207,9 +207,9 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
         int rel[CF_ITEMS];
         // 5 bits per item: halo row 0 / last row / column 0 / last column / beyond the 180 halo pixels.  A tile's edge pattern (the
         // same 5 bits: image missing above / below / left / right, and 1) replicated over the items and ANDed with this is non-zero
-        // exactly for the items whose LDS slot must be zero (conv_trunk.hip's scheme).  The producers get about one instruction
-        // issued per MFMA of the consumer wave on their SIMD (profiles/r03_trace_trunk_f32_fwd.txt: 5.4 us of producer work per
-        // 4.7 us stage made the consumers wait 0.55 us at every second barrier), so their instruction count is what is tuned here.
+        // exactly for the items whose LDS slot must be zero (conv_trunk.hip's scheme).  The producers' instructions compete with the
+        // consumer wave's MFMA stream for their SIMD's issue slots (profiles/r03_trace_trunk_f32_fwd.txt: 5.4 us of producer work
+        // per 4.7 us stage, the consumers 0.55 us at every second barrier), so their instruction count is what is tuned here.
         unsigned flags = 0;
 #pragma unroll
         for (int k = 0; k < CF_ITEMS; ++k) {
@@ -219,6 +219,7 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
             const unsigned f = (py == 0 ? 1u : 0u) | (py == CF_IH - 1 ? 2u : 0u) | (pxx == 0 ? 4u : 0u) | (pxx == CF_IW - 1 ? 8u : 0u) |
                                (px >= CF_NPIX ? 16u : 0u);
             flags |= f << (5 * k);
+            asm volatile("" : "+v"(rel[k]));                  // (opaque: kept in a register, not re-derived from m0 by every issue())
         }
         const bool last_beyond = m0 + 32 * (CF_ITEMS - 1) >= CF_NPIX;
         const int ldso = SPLIT ? m0 * CF_PSF * 4 + quad * 8 : (m0 * CF_PSF + quad * 4) * 4;

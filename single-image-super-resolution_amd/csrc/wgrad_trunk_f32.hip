@@ -171,8 +171,8 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         // (a tile lasts ~8 us of MFMAs; loading synchronously inside that window left the consumers waiting at 12 % of their
         // barriers' time for a late tile: tools/barrier_acct.py).  issue() is always executed -- past the last tile every offset
         // is out of range: an instruction, no traffic -- so that the loop has no control flow around loads.
-        // (instruction count of the producers is what is tuned here -- they get about one instruction issued per MFMA of the consumer
-        // wave on their SIMD, and the consumers of the exact kernel waited 10 % of the tile loop for them: no per-item address
+        // (instruction count of the producers is what is tuned here -- their instructions compete with the consumer wave's MFMA stream
+        // for the SIMD's issue slots, and the consumers of the exact kernel waited 10 % of the tile loop for them: no per-item address
         // selects (a buffer load past either end of the tensor returns zeros, one that lands on a neighbouring row's pixels
         // returns values commit() replaces by zeros), the edge test as one AND with the tile's replicated edge pattern, leaky
         // ReLU as max(v, slope v) for slopes in [0, 1], and interior tiles skip the zero selects)
