@@ -250,7 +250,9 @@ def test_tr16_lane_roles(L):
 
 
 BF16_CASES = [(2, 64, 64, 3, 1, 12, 12), (1, 64, 64, 3, 1, 37, 29), (2, 32, 128, 3, 1, 8, 8), (2, 128, 64, 3, 1, 6, 6),
-              (2, 64, 256, 3, 1, 16, 16), (2, 64, 128, 3, 2, 16, 16), (1, 64, 64, 3, 1, 96, 96)]
+              (2, 64, 256, 3, 1, 16, 16), (2, 64, 128, 3, 2, 16, 16), (1, 64, 64, 3, 1, 96, 96),
+              # the discriminator's deep layers (small maps, many channels: the planner's 32-cout tiles)
+              (4, 256, 512, 3, 1, 12, 12), (4, 512, 512, 3, 2, 12, 12), (3, 128, 256, 3, 2, 24, 24)]
 
 
 def _storage(monkeypatch, storage):
