@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     int a_base[2] = {0, 0};
     float bv = 0.f;
     float st_shift = 0.f, st_s1 = 0.f, st_s2 = 0.f;     // running statistics of this lane's values, shifted sums
+    f32x2 st_s1v = {0.f, 0.f}, st_s2v = {0.f, 0.f};     // (two partial sums each, packed arithmetic; joined into st_s1 / st_s2 after the loop)
     int st_n = 0;
     // ---- producer state: items idx = ptid + 256 k -> halo pixel idx / 8, channel octet ptid % 8 ----------------------
     const int ptid = tid & 255, oct = tid & 7;
@@ -431,13 +432,14 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
                             for (int i = 0; i < 16; ++i) sm += acc[i];
                             st_shift = sm * (1.f / 16.f) + bv;
                         }
+                        // (written on pairs so that it compiles to packed fp32 instructions: 6 per 4 values instead of ~14 -- this
+                        // wave's VALU instructions and the MFMA stream add up on the SIMD; two partial sums per lane, joined at the end)
                         const float st_c = bv - st_shift;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float dv = acc[4 * q + j] + st_c;
-                            st_s1 += dv;
-                            st_s2 += dv * dv;
-                        }
+                        const f32x2 c2 = {st_c, st_c};
+                        const f32x2 d01 = f32x2{acc[4 * q], acc[4 * q + 1]} + c2, d23 = f32x2{acc[4 * q + 2], acc[4 * q + 3]} + c2;
+                        st_s1v += d01; st_s1v += d23;
+                        st_s2v = __builtin_elementwise_fma(d01, d01, st_s2v);
+                        st_s2v = __builtin_elementwise_fma(d23, d23, st_s2v);
                         if (q == 3) st_n += 16;
                     }
                     bf16x4 hv;
@@ -578,6 +580,8 @@ __global__ void __launch_bounds__(TK_THREADS, 2) conv_trunk_fwd_kernel(const Tru
     // ---- one (count, mean, M2) partial per workgroup and channel ------------------------------------------------------
     if (a.stat_part != nullptr) {
         if (consumer) {
+            st_s1 = st_s1v[0] + st_s1v[1];
+            st_s2 = st_s2v[0] + st_s2v[1];
             float n = (float)st_n, mu = 0.f, m2 = 0.f;
             if (st_n > 0) {
                 const float m1 = st_s1 / n;
