@@ -62,8 +62,10 @@ typedef struct SisrConvPlan {
     int32_t lds_bytes;
     int32_t wpk_elems;              /* elements in the packed weight buffer                  */
     int32_t variant;                /* bf16 family, bit 0: the weight buffer carries the LANE-ORDER image of the persistent trunk
-                                       kernels behind the standard one (SisrWeightDesc.bf_f_lanes / bf_d_lanes); set by the caller
-                                       on the descriptor it launches, 0 after planning                      */
+                                       kernels behind the standard one (SisrWeightDesc.bf_f_lanes / bf_d_lanes); fp32 family, bits 1-2:
+                                       the LDS-order image behind the standard one (SisrWeightDesc.f_ldsimg / d_ldsimg: 2 = fp32
+                                       values, 4 = split pairs; used only when it matches mfma_split); set by the caller on the
+                                       descriptor it launches, 0 after planning                                  */
     /* bf16 family: reciprocals m = ceil(2^32 / d) (0 for d = 1) so that n / d = umulhi(n, m) for n, d < 2^16 --
      * the kernels' index arithmetic (tile id, tile row, LDS row) without integer division */
     uint32_t m_tiles_x, m_thw, m_tw, m_iw, m_wrow;
@@ -250,7 +252,13 @@ typedef struct SisrWeightDesc {
      * x 8 bf16 (in-channels (j >> 1) * 32 + (j & 1) * 16 + 8 kk ..) -- so that a wave's 16-byte loads are contiguous (1 KB per
      * instruction instead of 64 pieces 576 bytes apart: 1.1 us of every launch) */
     int32_t bf_f_lanes, bf_d_lanes;
+    /* fp32 images, trunk geometry (Cin = Cout = 64, 3x3): also write, right behind wpk_fwd / wpk_dgrad (SISR_WLDS_WORDS more
+     * 32-bit words), the weights in the persistent fp32-tensor conv kernel's LDS order -- [cout half][chunk][tap][cout 32][32 + 4
+     * words] -- so that its weight fill is a plain 16-byte copy.  1: fp32 values; 2: split build -- words 0..15 of a row the RNE
+     * bf16 heads of in-channels (2m, 2m + 1), words 16..31 the bf16 of what the heads leave; 0: none */
+    int32_t f_ldsimg, d_ldsimg;
 } SisrWeightDesc;
+#define SISR_WLDS_WORDS (2 * 2 * 9 * 32 * 36)
 
 /* max_rows / max_cols: largest Cout and Cin*KH*KW over the table (the launch grids are sized from them) */
 int sisr_weights_prepare(const SisrWeightDesc *table_dev, int32_t n, int32_t max_rows, int32_t max_cols,

@@ -71,7 +71,8 @@ class WeightDesc(C.Structure):
                                          'c_n_chunk', 'c_CoutPad')] +
                 [('wbf_fwd', _f), ('wbf_dgrad', _f), ('bf_f_CoutPad', _i32), ('bf_d_CoutPad', _i32),
                  ('bf_f_CK', _i32), ('bf_d_CK', _i32), ('wbf_dcls', _f * 4), ('bf_c_CoutPad', _i32 * 4),
-                 ('bf_f_lanes', _i32), ('bf_d_lanes', _i32)])
+                 ('bf_f_lanes', _i32), ('bf_d_lanes', _i32), ('f_ldsimg', _i32), ('d_ldsimg', _i32)])
+WLDS_WORDS = 2 * 2 * 9 * 32 * 36
 
 
 class WeightGradDesc(C.Structure):

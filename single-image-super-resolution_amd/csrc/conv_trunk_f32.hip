@@ -81,6 +81,7 @@ struct CTrunkF32Args {
     const float *pa, *pb, *pd, *ps, *pt;
     const float* slope_p; float slope;
     const float* wpk;
+    const void* wimg;                     // the weights in this kernel's LDS order (SisrWeightDesc.f_ldsimg / d_ldsimg), mode matching SPLIT, or nullptr
     const float* bias;
     const float* res;
     float* y;
@@ -163,6 +164,25 @@ __global__ void __launch_bounds__(CF_THREADS, 2) conv_trunk_f32_kernel(const CTr
     // before it ---
     auto fill_weights = [&]() {
         float* wl = reinterpret_cast<float*>(lds);
+        if (a.wimg != nullptr) {
+            // the image is this workgroup's weights region word for word ([chunk][tap][cout 32][32 + 4]): a 16-byte copy,
+            // all loads in flight, then the LDS writes
+            constexpr int UNITS = 2 * 9 * 32 * CF_WROW / 4;                     // 5184 16-byte units
+            constexpr int W_IT16 = (UNITS + CF_THREADS - 1) / CF_THREADS;         // 11
+            const cf_u32x4* src = reinterpret_cast<const cf_u32x4*>(a.wimg) + hc * UNITS;
+            cf_u32x4 wv16[W_IT16];
+#pragma unroll
+            for (int it = 0; it < W_IT16; ++it) {
+                const int u = tid + it * CF_THREADS;
+                wv16[it] = u < UNITS ? src[u] : cf_u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int it = 0; it < W_IT16; ++it) {
+                const int u = tid + it * CF_THREADS;
+                if (u < UNITS) reinterpret_cast<cf_u32x4*>(wl)[u] = wv16[it];
+            }
+            return;
+        }
         constexpr int W_IT = 2 * 9 * 32 * 32 / CF_THREADS;                     // 36 elements per thread
         float wv[W_IT];
 #pragma unroll
@@ -695,6 +715,9 @@ int sisr_conv2d_trunk_f32_launch(const SisrConvDesc* d, hipStream_t st) {
     a.x1 = d->x1; a.x2 = d->x2; a.x_out = d->x_out; a.pa = d->pa; a.pb = d->pb; a.pd = d->pd; a.ps = d->ps; a.pt = d->pt;
     a.slope_p = d->pro_slope_p; a.slope = d->pro_slope;
     a.wpk = d->wpk; a.bias = d->bias; a.res = d->res; a.y = d->y; a.stat_part = d->stat_part; a.cnt_part = d->cnt_part;
+    // the LDS-order image behind the standard one, when the caller packed it in the mode this launch computes in (trunk layers only)
+    const int img_mode = (d->plan.variant >> 1) & 3;
+    a.wimg = (d->Cin == 64 && d->Cout == 64 && img_mode == (d->mfma_split ? 2 : 1)) ? static_cast<const void*>(d->wpk + d->plan.wpk_elems) : nullptr;
     a.N = d->N; a.H = d->H; a.W = d->W;
     a.tiles_x = d->W / CF_TW; a.per_img = (d->H / CF_TH) * a.tiles_x; a.total = d->N * a.per_img;
     a.streams = cf_streams(d);

@@ -174,6 +174,46 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
             w.wpk_dgrad[e] = val;
         }
     }
+    // the fp32-tensor trunk conv's LDS-order images (SisrWeightDesc.f_ldsimg / d_ldsimg), behind the standard fp32 images
+    for (int role = 0; role < 2; ++role) {
+        const int mode = role == 0 ? w.f_ldsimg : w.d_ldsimg;
+        float* base = role == 0 ? w.wpk_fwd : w.wpk_dgrad;
+        if (mode == 0 || base == nullptr) continue;
+        const int64_t std_elems = role == 0 ? (int64_t)w.f_n_chunk * w.KH * w.f_CoutPad * w.f_KROWP
+                                            : (int64_t)w.d_n_chunk * w.KH * w.d_CoutPad * w.d_KROWP;
+        unsigned* dst = reinterpret_cast<unsigned*>(base + std_elems);
+        // value of (packed output channel oc, packed input channel ic, tap): the same numbers as the standard images hold
+        auto val = [&](int oc, int ic, int tap) {
+            const int r = tap / 3, sx = tap - 3 * r;
+            if (role == 0) return w.w_orig[(((int64_t)oc * w.Cin + ic) * w.KH + r) * w.KW + sx] * inv;
+            return w.w_orig[(((int64_t)ic * w.Cin + oc) * w.KH + (w.KH - 1 - r)) * w.KW + (w.KW - 1 - sx)] * inv;
+        };
+        for (int64_t e = start; e < SISR_WLDS_WORDS; e += stride) {
+            unsigned tq = (unsigned)e;
+            const int wd = (int)(tq % 36u); tq /= 36u;
+            const int co = (int)(tq & 31u); tq >>= 5;
+            const int tap = (int)(tq % 9u); tq /= 9u;
+            const int q = (int)(tq & 1u), hc = (int)(tq >> 1);
+            unsigned word = 0u;
+            if (wd < 32) {
+                const int oc = 32 * hc + co;
+                if (mode == 1) {
+                    word = __float_as_uint(val(oc, 32 * q + wd, tap));
+                } else {
+                    const int m = wd & 15;
+                    const float v0 = val(oc, 32 * q + 2 * m, tap), v1 = val(oc, 32 * q + 2 * m + 1, tap);
+                    const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+                    if (wd < 16) {
+                        word = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                    } else {
+                        const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
+                        word = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                    }
+                }
+            }
+            dst[e] = word;
+        }
+    }
     // bf16 images for conv_bf16.hip: [chunk32][cp][tap*32 + cl]
     if (w.wbf_fwd) {
         __bf16* dst = reinterpret_cast<__bf16*>(w.wbf_fwd);

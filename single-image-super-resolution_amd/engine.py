@@ -219,7 +219,19 @@ class ConvRef:
 
 class Prepared:
     """Per-forward products of sisr_weights_prepare for one conv (kept for the backward pass)."""
-    __slots__ = ('ref', 'plans', 'kinds', 'wpk_fwd', 'wpk_dgrad', 'sigma', 'u_used', 'v_used', 'lanes')
+    __slots__ = ('ref', 'plans', 'kinds', 'wpk_fwd', 'wpk_dgrad', 'sigma', 'u_used', 'v_used', 'lanes', 'ldsimg')
+
+
+def _trunk_ldsimg(gm, plan_f, plan_d, kinds):
+    """(forward, data-gradient) mode of the LDS-order weight image of the fp32-tensor trunk conv (SisrWeightDesc.f_ldsimg /
+    d_ldsimg): 0 none, 1 fp32 values, 2 split pairs -- for 3x3 64 -> 64 convs on the fp32 kernels"""
+    if os.environ.get('SISR_TRUNK_LDSIMG', '1') == '0' or gm.k != 3 or gm.cin != 64 or gm.cout != 64 or gm.stride != 1:
+        return 0, 0
+    mode = 2 if mfma_split() else 1
+    okf = not kinds[0] and plan_f.plan.CK == 32 and plan_f.plan.CoutPad == 64 and plan_f.plan.n_chunk == 2
+    okd = (plan_d is not None and not isinstance(plan_d, list) and not kinds[1] and plan_d.plan.CK == 32
+           and plan_d.plan.CoutPad == 64 and plan_d.plan.n_chunk == 2)
+    return (mode if okf else 0), (mode if okd else 0)
 
 
 def _trunk_lanes(gm, plan_f, plan_d, kinds):
@@ -243,8 +255,10 @@ def prepare_weights(items, training, need_dgrad=True):
     for ref, n, h, w in items:
         f, d, g, kinds = ref.geom.plans(n, h, w)
         lanes = _trunk_lanes(ref.geom, f, d, kinds)
+        ldsimg = _trunk_ldsimg(ref.geom, f, d, kinds)
         off_f = total
-        total += _align4(((f.plan.wpk_elems + 1) // 2) * (2 if lanes[0] else 1) if kinds[0] else f.plan.wpk_elems)   # bf16: 2 per float slot
+        total += _align4(((f.plan.wpk_elems + 1) // 2) * (2 if lanes[0] else 1) if kinds[0]
+                         else f.plan.wpk_elems + (L.WLDS_WORDS if ldsimg[0] else 0))   # bf16: 2 per float slot
         off_d = None
         if need_dgrad and isinstance(d, list):
             off_d = []
@@ -254,7 +268,8 @@ def prepare_weights(items, training, need_dgrad=True):
                     total += _align4((cls[0].plan.wpk_elems + 1) // 2 if cls[3] else cls[0].plan.wpk_elems)
         elif need_dgrad and d is not None:
             off_d = total
-            total += _align4(((d.plan.wpk_elems + 1) // 2) * (2 if lanes[1] else 1) if kinds[1] else d.plan.wpk_elems)
+            total += _align4(((d.plan.wpk_elems + 1) // 2) * (2 if lanes[1] else 1) if kinds[1]
+                             else d.plan.wpk_elems + (L.WLDS_WORDS if ldsimg[1] else 0))
         off_s = small
         rows_, cols_ = ref.geom.cout, ref.geom.cin * ref.geom.k * ref.geom.k
         small += 4 + (_align4(rows_) + _align4(cols_) if ref.u is not None else 0)
@@ -272,13 +287,16 @@ def prepare_weights(items, training, need_dgrad=True):
         p = Prepared()
         p.ref, p.plans, p.kinds = ref, (f, d, g), kinds
         p.lanes = _trunk_lanes(gm, f, d, kinds)
-        p.wpk_fwd = big[off_f:off_f + (((f.plan.wpk_elems + 1) // 2) * (2 if p.lanes[0] else 1) if kinds[0] else f.plan.wpk_elems)]
+        p.ldsimg = _trunk_ldsimg(gm, f, d, kinds)
+        p.wpk_fwd = big[off_f:off_f + (((f.plan.wpk_elems + 1) // 2) * (2 if p.lanes[0] else 1) if kinds[0]
+                                      else f.plan.wpk_elems + (L.WLDS_WORDS if p.ldsimg[0] else 0))]
         if isinstance(off_d, list):
             p.wpk_dgrad = [None if o is None else
                            big[o:o + ((cls[0].plan.wpk_elems + 1) // 2 if cls[3] else cls[0].plan.wpk_elems)]
                            for o, cls in zip(off_d, d)]
         else:
-            p.wpk_dgrad = (big[off_d:off_d + (((d.plan.wpk_elems + 1) // 2) * (2 if p.lanes[1] else 1) if kinds[1] else d.plan.wpk_elems)]
+            p.wpk_dgrad = (big[off_d:off_d + (((d.plan.wpk_elems + 1) // 2) * (2 if p.lanes[1] else 1) if kinds[1]
+                                             else d.plan.wpk_elems + (L.WLDS_WORDS if p.ldsimg[1] else 0))]
                            if off_d is not None else None)
         p.sigma = sm[off_s:off_s + 1]
         t = table[i]
@@ -289,11 +307,13 @@ def prepare_weights(items, training, need_dgrad=True):
             t.bf_f_lanes = int(p.lanes[0])
         else:
             t.wpk_fwd = p.wpk_fwd.data_ptr()
+            t.f_ldsimg = p.ldsimg[0]
         if kinds[1]:
             t.wbf_dgrad, t.bf_d_CoutPad, t.bf_d_CK = p.wpk_dgrad.data_ptr(), d.plan.CoutPad, d.plan.CK
             t.bf_d_lanes = int(p.lanes[1] and off_d is not None)
         else:
             t.wpk_dgrad = None if isinstance(p.wpk_dgrad, list) else _ptr(p.wpk_dgrad)
+            t.d_ldsimg = p.ldsimg[1] if (off_d is not None and not isinstance(off_d, list)) else 0
         t.Cout, t.Cin, t.KH, t.KW = gm.cout, gm.cin, gm.k, gm.k
         t.training, t.shuffle2 = int(training), int(gm.shuffle2)
         t.f_CK, t.f_PS, t.f_KROWP, t.f_n_chunk, t.f_CoutPad = (f.plan.CK, f.plan.PS, f.plan.KROWP,
@@ -429,7 +449,7 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
     f.y_bf16, f.res_bf16 = _bf(out), _bf(res)
     f.epi_act = epi
     f.mfma_split = mfma_split()
-    f.plan.variant = int(prep.lanes[0])
+    f.plan.variant = int(prep.lanes[0]) | (2 * prep.ldsimg[0])           # bit 0: lane-order bf16 image; bits 1-2: LDS-order fp32 image (mode)
     fin = op.fin
     if fin is not None and not fin.done:
         # deferred BatchNorm finalisation: by this conv when it runs on a persistent trunk kernel, else stand-alone first
@@ -524,7 +544,7 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
     d.wpk, d.bias, d.res, d.y = prep.wpk_dgrad.data_ptr(), None, _ptr(res), out.data_ptr()
     d.y_bf16, d.res_bf16 = _bf(out), _bf(res)
     d.mfma_split = mfma_split()
-    d.plan.variant = int(prep.lanes[1])
+    d.plan.variant = int(prep.lanes[1]) | (2 * prep.ldsimg[1])
     part = None
     if bnb is not None:
         x, consts, slope = bnb
