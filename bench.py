@@ -444,6 +444,17 @@ def config_work(kind, hr, lr, mask):
     return flops, nbytes
 
 
+def _fresh_allocator():
+    """every build / config of one bench process starts from an empty caching allocator: where the previous workload left its
+    blocks decides where this one's tensors land, and a replayed graph has been seen 15 % slower for it (cfg5 after the three
+    builds: 21 ms instead of 18 ms; not inside any timed region)"""
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+
 def bench_config(name, device, iters, log):
     """-> record of one config: ms per iteration, HR patches/s, its algorithmic work and roofline fractions"""
     import torch
@@ -452,6 +463,7 @@ def bench_config(name, device, iters, log):
     mg, md, mce, ut, op = (sub('model_generator'), sub('model_discriminator'), sub('model_content_extractor'), sub('utils'),
                            sub('optim'))
     E.set_precision('bf16')
+    _fresh_allocator()
     torch.manual_seed(0)
     if kind == 'progressive_x8':
         mp = sub('model_generator_progressive')
@@ -583,6 +595,7 @@ def main():
     builds = ['fp32', 'bf16x3', 'bf16'] if args.precision == 'both' else [args.precision]
     records = {}
     for prec in builds:
+        _fresh_allocator()
         dt, graphed, final_loss = timed_run(device, rank, world, prec, args.steps, args.warmup, not args.no_graph, log)
         if rank == 0:
             ms = dt / args.steps * 1e3
