@@ -215,7 +215,10 @@ int sisr_wgrad_toimage_eligible(const SisrWgradDesc *d);
 int sisr_wgrad_toimage_f32_eligible(const SisrWgradDesc *d);
 int sisr_conv2d_wgrad_f32(const SisrWgradDesc *d, void *stream);
 /* out[i] = sum_s slab[s][i], i < elems (also used for the bias slabs) */
-int sisr_slab_reduce_f32(const float *slab, float *out, int32_t n_slabs, int64_t elems, void *stream);
+int sisr_slab_reduce_f32(const float *slab, float *out, int32_t n_slabs, int64_t elems, int64_t lead_bf16, void *stream);
+/* lead_bf16: the first lead_bf16 elements of every row are stored as bf16 at the row's start (what the persistent bf16
+ * weight-gradient kernel writes: sisr_wgrad_bf16_slab_lead(d)), the rest -- the bias partials -- as fp32 at their float offset; 0: fp32 rows */
+int64_t sisr_wgrad_bf16_slab_lead(const SisrWgradDesc *d);
 
 /* ---- weights: spectral norm power iteration + packing (legacy torch.nn.utils.spectral_norm
  *      hook, model_generator.py:3; model_discriminator.py:2), multi-tensor: one launch serves
@@ -327,7 +330,7 @@ int sisr_bn_bwd_finalize(const SisrBnBwdDesc *d, void *stream);
  * a residual block (model_generator.py:16-19 differentiated), so one launch replaces two -- 33 fewer per step.  Both
  * results are bit-identical to the separate launches. */
 int sisr_bn_bwd_finalize_slab(const SisrBnBwdDesc *d, const float *slab, float *out, int32_t n_slabs, int64_t elems,
-                              void *stream);
+                              int64_t lead_bf16, void *stream);
 
 /* elementwise: y = f(x1) + (pa ? pa[c]*x2 + pd[c] : x2)   over NHWC [P][C];
  * f = lrelu(., slope1_p ? *slope1_p : slope1) -- the residual add of BasicBlock.forward (model_generator.py:19) and the

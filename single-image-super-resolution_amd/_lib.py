@@ -118,7 +118,8 @@ _SIGS = {
     'sisr_wgrad_plan_bf16': [C.POINTER(WgradDesc), _i32],
     'sisr_conv2d_wgrad_bf16': [C.POINTER(WgradDesc), _f],
     'sisr_tr16_selftest': [_f, _f],
-    'sisr_slab_reduce_f32': [_f, _f, _i32, _i64, _f],
+    'sisr_slab_reduce_f32': [_f, _f, _i32, _i64, _i64, _f],
+    'sisr_wgrad_bf16_slab_lead': [C.POINTER(WgradDesc)],
     'sisr_weights_prepare': [_f, _i32, _i32, _i32, _f],
     'sisr_weights_grad': [_f, _i32, _f, _i32, _f],
     'sisr_weights_grad_tiles': [C.POINTER(WeightGradDesc)],
@@ -127,7 +128,7 @@ _SIGS = {
     'sisr_bn_bwd_plan': [C.POINTER(BnBwdDesc)],
     'sisr_bn_bwd': [C.POINTER(BnBwdDesc), _f],
     'sisr_bn_bwd_finalize': [C.POINTER(BnBwdDesc), _f],
-    'sisr_bn_bwd_finalize_slab': [C.POINTER(BnBwdDesc), _f, _f, _i32, _i64, _f],
+    'sisr_bn_bwd_finalize_slab': [C.POINTER(BnBwdDesc), _f, _f, _i32, _i64, _i64, _f],
     'sisr_eltwise_res_affine': [_f, _f, _f32, _f, _f, _f, _f, _i64, _i32, _i32, _f],
     'sisr_prelu_slope_grad': [_f, _f, _i64, _f, _f, _i32, _f],
     'sisr_add': [_f, _f, _f, _i64, _i32, _f],
@@ -184,6 +185,7 @@ def lib():
         fn.argtypes = args
         fn.restype = C.c_int
     L.sisr_adam_blocks.restype = C.c_int64
+    L.sisr_wgrad_bf16_slab_lead.restype = C.c_int64
     L.sisr_version.restype = C.c_char_p
     L.sisr_version.argtypes = []
     sizes = (_i32 * 8)()

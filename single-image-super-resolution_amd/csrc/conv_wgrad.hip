@@ -172,9 +172,9 @@ __global__ void __launch_bounds__(SISR_BLOCK, 2) wgrad_mfma_f32_kernel(const Sis
 // resident): many short independent load chains beat few long ones.
 __global__ void __launch_bounds__(SISR_BLOCK) slab_reduce_kernel(const float* __restrict__ slab,
                                                                 float* __restrict__ out, int n_slabs,
-                                                                int64_t elems) {
+                                                                int64_t elems, int64_t lead) {
     __shared__ f32x4 sh[SR_SPLITS][SR_COLS];
-    slab_reduce_block(slab, out, n_slabs, elems, blockIdx.x, sh);
+    slab_reduce_block(slab, out, n_slabs, elems, blockIdx.x, sh, lead);
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -274,13 +274,13 @@ extern "C" int sisr_conv2d_wgrad_f32(const SisrWgradDesc* d, void* stream) {
     return SISR_E_UNSUPPORTED;
 }
 
-extern "C" int sisr_slab_reduce_f32(const float* slab, float* out, int32_t n_slabs, int64_t elems,
+extern "C" int sisr_slab_reduce_f32(const float* slab, float* out, int32_t n_slabs, int64_t elems, int64_t lead_bf16,
                                     void* stream) {
     if (!slab || !out || n_slabs <= 0 || elems <= 0) return SISR_E_BADARG;
-    if (elems & 3) return SISR_E_BADARG;   // slab strides are multiples of 4 floats (16-byte loads)
+    if ((elems & 3) || (lead_bf16 & 3) || lead_bf16 < 0 || lead_bf16 > elems) return SISR_E_BADARG;   // 16-byte units
     const int blocks = (int)((elems / 4 + SR_COLS - 1) / SR_COLS);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(SISR_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
-                       slab, out, n_slabs, elems);
+                       slab, out, n_slabs, elems, lead_bf16);
     SISR_CHECK_LAUNCH();
     return 0;
 }

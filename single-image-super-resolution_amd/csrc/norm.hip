@@ -177,12 +177,12 @@ __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_finalize_kernel(const SisrB
 // weight gradient computed just before (sisr_bn_bwd_finalize_slab)
 __global__ void __launch_bounds__(SISR_BLOCK) bn_bwd_finalize_slab_kernel(const SisrBnBwdDesc d, int fin_blocks,
                                                                          const float* __restrict__ slab, float* __restrict__ out,
-                                                                         int n_slabs, int64_t elems) {
+                                                                         int n_slabs, int64_t elems, int64_t lead) {
     if ((int)blockIdx.x < fin_blocks) {
         bn_bwd_finalize_block(d, blockIdx.x);
     } else {
         __shared__ f32x4 sh[SR_SPLITS][SR_COLS];
-        slab_reduce_block(slab, out, n_slabs, elems, (int)blockIdx.x - fin_blocks, sh);
+        slab_reduce_block(slab, out, n_slabs, elems, (int)blockIdx.x - fin_blocks, sh, lead);
     }
 }
 
@@ -345,15 +345,15 @@ extern "C" int sisr_bn_bwd_finalize(const SisrBnBwdDesc* d, void* stream) {
 }
 
 extern "C" int sisr_bn_bwd_finalize_slab(const SisrBnBwdDesc* d, const float* slab, float* out, int32_t n_slabs, int64_t elems,
-                                         void* stream) {
+                                         int64_t lead_bf16, void* stream) {
     if (!d || !d->invstd || !d->mean || !d->gamma || !d->work || !d->qa || !d->qb || !d->qd || !d->dgamma || !d->dbeta ||
         d->grid <= 0 || d->C <= 0 || d->P <= 0)
         return SISR_E_BADARG;
-    if (!slab || !out || n_slabs <= 0 || elems <= 0 || (elems & 3)) return SISR_E_BADARG;
+    if (!slab || !out || n_slabs <= 0 || elems <= 0 || (elems & 3) || (lead_bf16 & 3) || lead_bf16 < 0 || lead_bf16 > elems) return SISR_E_BADARG;
     const int fin_blocks = (d->C + BWF_CH - 1) / BWF_CH;
     const int slab_blocks = (int)((elems / 4 + SR_COLS - 1) / SR_COLS);
     hipLaunchKernelGGL(bn_bwd_finalize_slab_kernel, dim3(fin_blocks + slab_blocks), dim3(SISR_BLOCK), 0, S_(stream), *d, fin_blocks,
-                       slab, out, n_slabs, elems);
+                       slab, out, n_slabs, elems, lead_bf16);
     SISR_CHECK_LAUNCH();
     return 0;
 }

@@ -43,16 +43,29 @@ static inline int sisr_raise_lds_cap(SisrLdsCap& cap, const void* fn, int bytes,
 // many short independent load chains beat few long ones
 #define SR_COLS 16
 #define SR_SPLITS (SISR_BLOCK / SR_COLS)
+// lead (a multiple of 4, 0: none): the first `lead` elements of every row are stored as bf16 at the row's start (the persistent
+// bf16 weight-gradient kernel's slabs: half the bytes written and re-read); the rest of the row -- the bias partials -- as fp32
+// at their usual float offset
 __device__ __forceinline__ void slab_reduce_block(const float* __restrict__ slab, float* __restrict__ out, int n_slabs,
-                                                  int64_t elems, int block, f32x4 (*sh)[SR_COLS]) {
+                                                  int64_t elems, int block, f32x4 (*sh)[SR_COLS], int64_t lead = 0) {
     const int col = threadIdx.x & (SR_COLS - 1), split = threadIdx.x / SR_COLS;
     const int64_t i4 = (int64_t)block * SR_COLS + col;
     const int64_t n4 = elems >> 2;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i4 < n4) {
+        if (i4 * 4 < lead) {
+            typedef unsigned sr_u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll 8
-        for (int k = split; k < n_slabs; k += SR_SPLITS)
-            s += *reinterpret_cast<const f32x4*>(slab + (int64_t)k * elems + i4 * 4);
+            for (int k = split; k < n_slabs; k += SR_SPLITS) {
+                const sr_u32x2 w = *reinterpret_cast<const sr_u32x2*>(reinterpret_cast<const unsigned short*>(slab + (int64_t)k * elems) + i4 * 4);
+                s[0] += __uint_as_float(w[0] << 16); s[1] += __uint_as_float(w[0] & 0xFFFF0000u);
+                s[2] += __uint_as_float(w[1] << 16); s[3] += __uint_as_float(w[1] & 0xFFFF0000u);
+            }
+        } else {
+#pragma unroll 8
+            for (int k = split; k < n_slabs; k += SR_SPLITS)
+                s += *reinterpret_cast<const f32x4*>(slab + (int64_t)k * elems + i4 * 4);
+        }
     }
     sh[split][col] = s;
     __syncthreads();

@@ -67,6 +67,7 @@ struct WTrunkArgs {
     // PixelShuffle phases, workgroup b serves group b % 4 on tile stream b / 4; the gradient operand of group (i, j) is the
     // strided view pixel (2 y + i, 2 x + j) of the [N][2H][2W][64] tensor.  A stream's four workgroups share one slab.
     int glog, cout_pad, gshuffle;
+    int slab_bf16;                          // the gradient part of a slab row is stored as bf16 at the row's start (sisr_wgrad_bf16_slab_lead)
 };
 
 __device__ __forceinline__ bf16x8 wt_frag(const unsigned char* p) {
@@ -333,7 +334,11 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sl[((gq * 9 + t) * 32 + mfma_row(i, lane)) * a.cout_pad + 64 * cg + 32 * h + l31] = acc[t][i];
+            for (int i = 0; i < 16; ++i) {
+                const int idx = ((gq * 9 + t) * 32 + mfma_row(i, lane)) * a.cout_pad + 64 * cg + 32 * h + l31;
+                if (a.slab_bf16) reinterpret_cast<__bf16*>(sl)[idx] = (__bf16)acc[t][i];
+                else sl[idx] = acc[t][i];
+            }
     }
     if (a.bias_slab != nullptr) {                       // ... and its bias row
         __syncthreads();
@@ -384,6 +389,20 @@ extern "C" int sisr_wgrad_trunk_eligible(const SisrWgradDesc* d) {
 extern "C" int sisr_wgrad_toimage_eligible(const SisrWgradDesc* d);
 int sisr_wgrad_toimage_slabs(const SisrWgradDesc* d);                         // wgrad_toimage.hip
 
+// The persistent kernel writes the gradient part of its slabs as bf16 (231 slabs x 147 KB written and re-read per layer were
+// two thirds of the finishing launch; a partial sum rounded to bf16 costs up to ~2e-3 relative on a cancelling total, inside this
+// build's error budget -- its tensors are bf16).  SISR_SLAB_BF16=0 keeps fp32 slabs (A/B).
+static bool wtrunk_slab_bf16() {
+    const char* e = getenv("SISR_SLAB_BF16");
+    return !(e && e[0] == '0');
+}
+// leading elements of every slab row that the launch of `d` stores as bf16 (pass it to sisr_slab_reduce_f32 /
+// sisr_bn_bwd_finalize_slab); 0: fp32 slabs
+extern "C" int64_t sisr_wgrad_bf16_slab_lead(const SisrWgradDesc* d) {
+    if (!d) return 0;
+    return sisr_wgrad_trunk_eligible(d) && wtrunk_slab_bf16() ? (int64_t)d->slab_elems : 0;
+}
+
 extern "C" int sisr_wgrad_bf16_slabs(const SisrWgradDesc* d) {
     if (!d) return SISR_E_BADARG;
     if (sisr_wgrad_trunk_eligible(d)) return wtrunk_grid(d) / (d->Cout == 256 ? 4 : 1);
@@ -417,6 +436,7 @@ int sisr_wgrad_trunk_launch(const SisrWgradDesc* d, hipStream_t st) {
     a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);
     a.xpro = d->pro_mode;
     a.glog = d->Cout == 256 ? 2 : 0; a.cout_pad = d->Cout == 256 ? 256 : 64; a.gshuffle = d->g_mode == SISR_X_NHWC_UNSHUFFLE2 ? 1 : 0;
+    a.slab_bf16 = wtrunk_slab_bf16() ? 1 : 0;
     const int grid = wtrunk_grid(d);
     if (d->gpro_mode == SISR_PRO_ACT_BWD) return launch_wtrunk<SISR_PRO_ACT_BWD>(a, grid, st);
     if (d->gpro_mode == SISR_PRO_BNBWD) return launch_wtrunk<SISR_PRO_BNBWD>(a, grid, st);

@@ -579,7 +579,7 @@ class PendingSlabs:
     left the ordinary way.  The reduced buffers are valid in stream order after either."""
 
     def __init__(self):
-        self.jobs = []                      # (slab tensor, reduced tensor, n_slabs, stride)
+        self.jobs = []                      # (slab tensor, reduced tensor, n_slabs, stride, leading bf16 elements per row)
 
     def pop(self):
         return self.jobs.pop(0) if self.jobs else None
@@ -587,8 +587,8 @@ class PendingSlabs:
     def flush(self):
         lib = L.lib()
         while self.jobs:
-            slab, red, n_slabs, stride = self.jobs.pop(0)
-            L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), red.data_ptr(), n_slabs, stride, _stream()),
+            slab, red, n_slabs, stride, lead = self.jobs.pop(0)
+            L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), red.data_ptr(), n_slabs, stride, lead, _stream()),
                     'sisr_slab_reduce_f32')
 
 
@@ -620,6 +620,7 @@ def conv_wgrad(prep, x_op, dy_op, defer=None):
     dy_op.fill(g, g=True)
     g.mfma_split = mfma_split()
     n_slabs = (lib.sisr_wgrad_bf16_slabs if prep.kinds[2] else lib.sisr_wgrad_f32_slabs)(C.byref(g))
+    lead = int(lib.sisr_wgrad_bf16_slab_lead(C.byref(g))) if prep.kinds[2] else 0     # the persistent bf16 kernel's slabs are bf16
     slab = torch.empty((n_slabs, stride), dtype=torch.float32, device=dev)
     g.slab = slab.data_ptr()
     g.bias_slab = slab.data_ptr() + 4 * g.slab_elems
@@ -629,9 +630,9 @@ def conv_wgrad(prep, x_op, dy_op, defer=None):
         L.check(lib.sisr_conv2d_wgrad_f32(C.byref(g), _stream()), 'sisr_conv2d_wgrad_f32')
     red = torch.empty((stride,), dtype=torch.float32, device=dev)
     if defer is not None and os.environ.get('SISR_FUSE_SLABRED', '1') != '0':
-        defer.jobs.append((slab, red, n_slabs, stride))
+        defer.jobs.append((slab, red, n_slabs, stride, lead))
         return red
-    L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), red.data_ptr(), n_slabs, stride, _stream()),
+    L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), red.data_ptr(), n_slabs, stride, lead, _stream()),
             'sisr_slab_reduce_f32')
     return red
 
@@ -767,8 +768,8 @@ def bn_backward(dy, x, consts, gamma, slope=None, part=None, slabs=None):
     else:
         job = slabs.pop() if slabs is not None else None
         if job is not None:                     # this launch also sums the slabs of the weight gradient computed before it
-            slab, red, n_slabs, stride = job
-            L.check(lib.sisr_bn_bwd_finalize_slab(C.byref(d), slab.data_ptr(), red.data_ptr(), n_slabs, stride, _stream()),
+            slab, red, n_slabs, stride, lead = job
+            L.check(lib.sisr_bn_bwd_finalize_slab(C.byref(d), slab.data_ptr(), red.data_ptr(), n_slabs, stride, lead, _stream()),
                     'sisr_bn_bwd_finalize_slab')
         else:
             L.check(lib.sisr_bn_bwd_finalize(C.byref(d), _stream()), 'sisr_bn_bwd_finalize')

@@ -386,11 +386,11 @@ def test_bn_backward_finish_carries_a_slab_reduction(E, L):
     for n_slabs, stride in ((231, 36928), (7, 20), (40, 16 * 4 * 5 + 4)):
         slab = (torch.rand(n_slabs, stride, generator=g) - 0.5).cuda()
         want_red = torch.empty(stride, device='cuda')
-        L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), want_red.data_ptr(), n_slabs, stride, st), 'slab_reduce')
+        L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), want_red.data_ptr(), n_slabs, stride, 0, st), 'slab_reduce')
         want = E.bn_backward(x, x, consts, gamma, slope=slope, part=part)
         pend = E.PendingSlabs()
         red = torch.full((stride,), float('nan'), device='cuda')
-        pend.jobs.append((slab, red, n_slabs, stride))
+        pend.jobs.append((slab, red, n_slabs, stride, 0))
         got = E.bn_backward(x, x, consts, gamma, slope=slope, part=part, slabs=pend)
         assert pend.jobs == []
         assert torch.equal(red, want_red)
@@ -565,7 +565,7 @@ def test_trunk_kernel_weight_gradient_role(E, L, shape, xpro, gpro, monkeypatch)
         for sw in ('1', '0'):
             monkeypatch.setenv('SISR_TRUNK_WGRAD', sw)
             red[sw] = E.conv_wgrad(p, x_op, dy_op)
-        assert maxrel(red['1'], red['0']) < 2e-3                     # same products, different fp32 summation order
+        assert maxrel(red['1'], red['0']) < 5e-3                     # same products; the persistent kernel's partial sums are stored as bf16 (2^-9 each)
         wg = E.WeightGradBatch()
         wg.add(p, red['1'])
         gw, gb = wg.run()[id(ref)]
@@ -880,7 +880,7 @@ def test_trunk_kernel_upscale_conv_weight_gradient(E, L, shape, monkeypatch):
         for sw in ('1', '0'):
             monkeypatch.setenv('SISR_TRUNK_UP', sw)
             red[sw] = E.conv_wgrad(p, x_op, dy_op)
-        assert maxrel(red['1'], red['0']) < 2e-3
+        assert maxrel(red['1'], red['0']) < 5e-3     # (the persistent kernel's per-workgroup partial sums are stored as bf16: 2^-9 each)
         wg = E.WeightGradBatch()
         wg.add(p, red['1'])
         gw, gb = wg.run()[id(ref)]
