@@ -239,6 +239,17 @@ def test_trunk_kernels_claim_exactly_their_descriptors(monkeypatch):
         # SISR_PERSIST_MAX_WG caps the grid of every persistent kernel (the multi-tile test knob)
         monkeypatch.delenv('SISR_TRUNK')
         monkeypatch.delenv('SISR_TRUNK_UP')
+        # the persistent weight-gradient kernel stores the gradient part of its slabs as bf16: the reduction must be told
+        g = L.WgradDesc.from_buffer_copy(E.ConvGeom(64, 64, 3, 1, 1).plans(16, 96, 96)[2])
+        g.x1 = g.g1 = g.g2 = g.slab = g.qa = g.qb = g.qd = one
+        g.x_bf16 = g.g_bf16 = 1
+        g.gpro_mode = L.PRO_BNBWD
+        assert lib.sisr_wgrad_trunk_eligible(g) == 1 and lib.sisr_wgrad_bf16_slab_lead(g) == g.slab_elems and g.slab_elems % 4 == 0
+        monkeypatch.setenv('SISR_SLAB_BF16', '0')
+        assert lib.sisr_wgrad_bf16_slab_lead(g) == 0
+        monkeypatch.delenv('SISR_SLAB_BF16')
+        g.g_bf16 = 0
+        assert lib.sisr_wgrad_trunk_eligible(g) == 0 and lib.sisr_wgrad_bf16_slab_lead(g) == 0     # generic kernel: fp32 slabs
         f.pro_mode, f.x2, f.x_out = L.PRO_NONE, None, None
         monkeypatch.setenv('SISR_PERSIST_MAX_WG', '5')
         assert lib.sisr_conv2d_bf16_parts(f) <= 5

@@ -396,6 +396,23 @@ def test_bn_backward_finish_carries_a_slab_reduction(E, L):
         assert torch.equal(red, want_red)
         for a, b in zip(got, want):
             assert torch.equal(a, b)
+    # rows whose first `lead` elements are bf16 at the row's start (the persistent bf16 weight-gradient kernel's slabs), the rest
+    # fp32 at their float offset: exactly the sum of the values as stored, through both entry points
+    for n_slabs, stride, lead in ((231, 36928, 36864), (9, 48, 32), (40, 16 * 4 * 5 + 4, 16 * 4 * 4)):
+        vals = torch.rand(n_slabs, stride, generator=g) - 0.5
+        lead_vals = vals[:, :lead].bfloat16()
+        slab = (torch.rand(n_slabs, stride, generator=g) * 1e6).cuda()                 # (the hole behind the bf16 part holds junk)
+        slab[:, lead:] = vals[:, lead:].cuda()
+        slab.view(torch.bfloat16)[:, :lead] = lead_vals.cuda()
+        want_red = torch.cat([lead_vals.double().sum(0), vals[:, lead:].double().sum(0)])
+        red = torch.full((stride,), float('nan'), device='cuda')
+        L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), red.data_ptr(), n_slabs, stride, lead, st), 'slab_reduce (bf16 lead)')
+        assert maxrel(red, want_red) < 1e-5
+        pend = E.PendingSlabs()
+        red2 = torch.full((stride,), float('nan'), device='cuda')
+        pend.jobs.append((slab, red2, n_slabs, stride, lead))
+        E.bn_backward(x, x, consts, gamma, slope=slope, part=part, slabs=pend)
+        assert torch.equal(red2, red)
 
 
 def _merged_stats(sp, cp):
