@@ -71,6 +71,29 @@ typedef struct SisrConvPlan {
     uint32_t m_tiles_x, m_thw, m_tw, m_iw, m_wrow;
 } SisrConvPlan;
 
+/* Plan of the split-K implicit-GEMM kernels of conv_deep.hip (bf16 build; filled by sisr_conv2d_deep_plan): the layers whose
+ * contraction is deep and whose images are small -- the discriminator's strided-conv stack (model_discriminator.py:10,39-44), the
+ * VGG19 feature convs (model_content_extractor.py:43) and the generator's trunk at sizes the persistent trunk kernels do not take.
+ * A workgroup owns 128 output pixels x BN output channels x one K slice (a range of 32-channel chunks); an output tile is TH rows of
+ * the FLATTENED (image, output row) space x TW columns, so that a band of full-width rows may straddle images (12 x 12 and 6 x 6 maps
+ * fill 120 / 126 of the 128 MFMA rows); with split > 1 every workgroup leaves its fp32 partial tile in `ws` and
+ * conv_deep_finish_kernel sums the slices in a fixed order and runs the epilogue (bias, statistics, reductions, bf16 store). */
+typedef struct SisrDeepPlan {
+    int32_t enabled;                /* 1: sisr_conv2d_bf16 runs this descriptor on conv_deep.hip            */
+    int32_t TH, TW;                 /* output tile: TH flattened output rows x TW columns (<= 128 pixels)   */
+    int32_t tiles_x, tiles_q;       /* column tiles, row-band tiles                                         */
+    int32_t BN, n_ntiles;           /* output channels per workgroup (64 | 128), cout tiles                 */
+    int32_t n_chunk, split, cps;    /* 32-channel chunks, K slices, chunks per slice                        */
+    int32_t PR;                     /* padded input rows per image (pad_y + H + bottom padding)             */
+    int32_t IW, IH_max;             /* halo tile: columns, most rows of any tile                            */
+    int32_t NIT;                    /* 16-byte staging items per thread                                     */
+    int32_t wimg_elems;             /* bf16 elements of the weight image [chunk][tap row][Cout][KW*32 + 8]  */
+    int32_t rsv;
+    int64_t ws_bytes;               /* bytes of the split workspace (0 when split == 1)                     */
+    uint32_t m_tiles_x, m_tw, m_ho, m_pr, m_iw;
+    uint32_t rsv2;
+} SisrDeepPlan;
+
 /* Direct convolution, fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32) accumulate.
  * Replaces nn.Conv2d forward and its data-gradient (model_generator.py:10,13,33,39,45,52,123;
  * model_discriminator.py:10,39; torchvision VGG19 convs via model_content_extractor.py:43) with
@@ -121,6 +144,13 @@ typedef struct SisrConvDesc {
      * fp32 operand (hi*hi + hi*lo + lo*hi, fp32 accumulate; operands good to 2^-17 relative); 0 = exact fp32 matrix instruction */
     int32_t mfma_split;
     SisrConvPlan plan;
+    /* conv_deep.hip (see SisrDeepPlan): `wdeep` = the weight image in that family's layout (SisrWeightDesc.wdp_fwd / wdp_dgrad),
+     * `deep_ws` = the caller's split workspace (deep.ws_bytes; may be NULL when deep.split == 1), `epi_scale_p` = device scalar the
+     * accumulators are multiplied by before the bias (1 / sigma of a spectrally normalised weight packed un-normalised) or NULL */
+    const void *wdeep;
+    float *deep_ws;
+    const float *epi_scale_p;
+    SisrDeepPlan deep;
 } SisrConvDesc;
 
 int sisr_conv2d_plan(SisrConvDesc *d);                        /* host only: fills d->plan     */
@@ -162,6 +192,13 @@ int sisr_wgrad_plan(SisrWgradDesc *d, int32_t max_pixel_blocks);
  * operands; SISR_E_UNSUPPORTED otherwise (callers keep the fp32 kernels for those layers). */
 int sisr_conv2d_plan_bf16(SisrConvDesc *d);
 int sisr_conv2d_bf16(const SisrConvDesc *d, void *stream);
+/* conv_deep.hip: fills d->deep for a descriptor whose geometry / modes are set (after sisr_conv2d_plan_bf16); returns
+ * SISR_E_UNSUPPORTED (and leaves deep.enabled = 0) for geometries that family does not take: Cin % 32, Cout % 64, taps <= 3 x 3,
+ * stride 1 | 2, NHWC bf16 in and out.  target_wg: workgroups a launch should reach through the K split (0: default 256).
+ * sisr_conv2d_bf16 dispatches to it when deep.enabled && wdeep; sisr_conv2d_bf16_parts counts its partial rows. */
+int sisr_conv2d_deep_plan(SisrConvDesc *d, int32_t target_wg);
+/* a fully filled descriptor (storage flags, modes, fusions, wdeep, deep_ws) will run on conv_deep.hip */
+int sisr_conv2d_deep_eligible(const SisrConvDesc *d);
 /* The generator's trunk geometry (3x3, 64 -> 64, stride 1, bf16 NHWC in and out, H % 8 == 0, W % 16 == 0; forward-type
  * prologue, no residual) runs on a persistent weights-in-registers kernel (conv_trunk.hip) behind sisr_conv2d_bf16;
  * sisr_conv2d_trunk_eligible tells whether a fully filled descriptor will.  That kernel writes ONE statistics partial
@@ -227,7 +264,7 @@ typedef struct SisrWeightDesc {
     const float *w_orig;      /* OIHW [Cout][Cin][KH][KW]                                     */
     float *u, *v;             /* spectral-norm buffers (updated in place when training) or NULL */
     float *u_used, *v_used;   /* copies of the u/v that define sigma (for backward) or NULL   */
-    float *sigma;             /* [1] out (1.0 when u == NULL)                                 */
+    float *sigma;             /* [2] out: sigma (1.0 when u == NULL), 1 / sigma                */
     float *sn_work;           /* power-iteration scratch, >= ceil(Cout/16)*Cin*KH*KW + Cout floats (u != NULL) */
     float *wpk_fwd;           /* packed W/sigma for the forward conv, or NULL                 */
     float *wpk_dgrad;         /* packed flipped/transposed W/sigma for the data gradient, or NULL */
@@ -260,12 +297,27 @@ typedef struct SisrWeightDesc {
      * words] -- so that its weight fill is a plain 16-byte copy.  1: fp32 values; 2: split build -- words 0..15 of a row the RNE
      * bf16 heads of in-channels (2m, 2m + 1), words 16..31 the bf16 of what the heads leave; 0: none */
     int32_t f_ldsimg, d_ldsimg;
+    /* conv_deep.hip images (or NULL): [32-channel chunk][tap row][cout][KW * 32 + 8] bf16, element kx * 32 + ci; the data-gradient
+     * image has the roles of the channels swapped and the taps flipped; wdp_dcls = the four output-parity classes of a stride-2
+     * convolution's data gradient (taps c_KH x c_KW, tap (r', s') = forward tap (c_R0y - 2 r', c_R0x - 2 s')).  wdp_scaled = 0 packs
+     * W_orig itself (the kernels then apply 1 / sigma in their epilogue: SisrConvDesc.epi_scale_p), 1 packs W_orig / sigma */
+    void *wdp_fwd, *wdp_dgrad;
+    void *wdp_dcls[4];
+    int32_t wdp_scaled, wdp_rsv;
 } SisrWeightDesc;
 #define SISR_WLDS_WORDS (2 * 2 * 9 * 32 * 36)
 
 /* max_rows / max_cols: largest Cout and Cin*KH*KW over the table (the launch grids are sized from them) */
 int sisr_weights_prepare(const SisrWeightDesc *table_dev, int32_t n, int32_t max_rows, int32_t max_cols,
                          void *stream);
+
+/* sisr_weights_prepare = sisr_weights_sn (power iteration: u, v, sigma; sigma[1] = 1 / sigma) + sisr_weights_pack (every image but
+ * the wdp_* ones).  sisr_weights_pack_deep writes the conv_deep.hip images (wdp_fwd / wdp_dgrad / wdp_dcls, 3x3 weights) from one
+ * coalesced read of each 32 x 32-channel tile; max_cout / max_cin: largest channel counts over the table.  A caller that keeps
+ * un-normalised images (wdp_scaled = 0) across the forwards between two optimizer steps runs sisr_weights_sn alone. */
+int sisr_weights_sn(const SisrWeightDesc *table_dev, int32_t n, int32_t max_rows, int32_t max_cols, void *stream);
+int sisr_weights_pack(const SisrWeightDesc *table_dev, int32_t n, int32_t max_rows, int32_t max_cols, void *stream);
+int sisr_weights_pack_deep(const SisrWeightDesc *table_dev, int32_t n, int32_t max_cout, int32_t max_cin, void *stream);
 
 /* Weight-gradient epilogue: packed dW (sum of slabs) -> OIHW gradient of w_orig, through the
  * spectral-norm quotient: dW_orig = (G - <G, W> u v^T) / sigma  (autograd of W = W_orig/sigma with
@@ -392,6 +444,18 @@ int sisr_fc_dgrad(const float *dy, const float *W, float *dx, float *work, int32
 /* dW[n][k] = sum_b dy[b][n] * lrelu(x[b][k], in_slope); db[n] = sum_b dy[b][n] */
 int sisr_fc_wgrad(const float *dy, const float *x, float in_slope, float *dW, float *db, int32_t B,
                   int32_t K, int32_t Nout, void *stream);
+/* The whole classifier head of D (model_discriminator.py:47-53: Linear(K, N) -> LeakyReLU -> Linear(N, 1) -> Sigmoid) on the
+ * exact-fp32 matrix instruction (fc_head.hip), B <= 16, K % 16 == 0 (forward) / K % 64 == 0 (data gradient), N % 128 == 0:
+ *   forward:  h1 [B][N] = x W1^T + b1 (pre-activation, kept for the backward), y [B] = sigmoid(lrelu(h1, slope) . W2 + b2);
+ *             ws: sisr_fc_head_ws_floats(N) floats.  W2 == NULL: first layer only.
+ *   backward: from g [B] = dL/dy: d1 [B][N] = dL/dh1, dW2 [N], db2 [1], db1 [N]  (everything that is not W1-sized);
+ *   sisr_fc1_dgrad: dx [B][K] = d1 W1.   dW1 = d1^T x stays with sisr_fc_wgrad (an outer product: write-bound). */
+int sisr_fc_head_ws_floats(int32_t N);
+int sisr_fc_head_forward(const float *x, const float *W1, const float *b1, const float *W2, const float *b2, float slope,
+                         float *h1, float *y, float *ws, int32_t B, int32_t K, int32_t N, void *stream);
+int sisr_fc_head_backward(const float *g, const float *y, const float *h1, const float *W2, float slope, float *d1,
+                          float *dW2, float *db2, float *db1, int32_t B, int32_t N, void *stream);
+int sisr_fc1_dgrad(const float *d1, const float *W1, float *dx, int32_t B, int32_t K, int32_t N, void *stream);
 /* elementwise helpers for the tiny FC activations: dy_pre = dy * act'(...) */
 int sisr_act_bwd(const float *dy, const float *ref, float *out, int64_t n, int32_t kind, float slope,
                  void *stream);   /* kind 0: leaky (ref = pre-activation), 1: sigmoid (ref = output) */
@@ -436,7 +500,7 @@ int sisr_adam_step(const SisrAdamDesc *table_dev, int32_t n, int64_t total_block
                    double eps, double weight_decay, double bias_corr1, double bias_corr2, void *stream);
 
 /* sizeof() of the descriptor structs in declaration order (Conv, Wgrad, Weight, WeightGrad,
- * BnBwd, ConvPlan) so a binding can verify its mirror of this header; returns the count. */
+ * BnBwd, ConvPlan, DeepPlan) so a binding can verify its mirror of this header; returns the count. */
 int sisr_struct_sizes(int32_t *out, int32_t cap);
 int sisr_device_info(int32_t *n_cu, int32_t *lds_per_cu, char *arch, int32_t arch_len);
 int sisr_mfma_selftest(float *out_dev /* >= 32*32 floats */, void *stream);

@@ -30,6 +30,13 @@ class ConvPlan(C.Structure):
         (n, C.c_uint32) for n in ('m_tiles_x', 'm_thw', 'm_tw', 'm_iw', 'm_wrow')]
 
 
+class DeepPlan(C.Structure):
+    _fields_ = ([(n, _i32) for n in ('enabled', 'TH', 'TW', 'tiles_x', 'tiles_q', 'BN', 'n_ntiles', 'n_chunk', 'split', 'cps',
+                                     'PR', 'IW', 'IH_max', 'NIT', 'wimg_elems', 'rsv')] +
+                [('ws_bytes', _i64)] +
+                [(n, C.c_uint32) for n in ('m_tiles_x', 'm_tw', 'm_ho', 'm_pr', 'm_iw', 'rsv2')])
+
+
 class ConvDesc(C.Structure):
     _fields_ = ([(n, _f) for n in ('x1', 'x2', 'pa', 'pb', 'pd', 'ps', 'pt', 'wpk', 'bias', 'res', 'y',
                                    'stat_part', 'cnt_part', 'bnb_x', 'bnb_scale', 'bnb_shift', 'bnb_mean',
@@ -42,7 +49,8 @@ class ConvDesc(C.Structure):
                 [(n, _i32) for n in ('y_sy', 'y_oy', 'y_sx', 'y_ox', 'y_H', 'y_W')] +
                 [(n, _i32) for n in ('x_bf16', 'y_bf16', 'res_bf16', 'bnbx_bf16')] +
                 [('fin_rows', _i32), ('fin_momentum', _f32), ('fin_eps', _f32), ('mfma_split', _i32)] +
-                [('plan', ConvPlan)])
+                [('plan', ConvPlan)] +
+                [('wdeep', _f), ('deep_ws', _f), ('epi_scale_p', _f), ('deep', DeepPlan)])
 
 
 class WgradDesc(C.Structure):
@@ -71,7 +79,8 @@ class WeightDesc(C.Structure):
                                          'c_n_chunk', 'c_CoutPad')] +
                 [('wbf_fwd', _f), ('wbf_dgrad', _f), ('bf_f_CoutPad', _i32), ('bf_d_CoutPad', _i32),
                  ('bf_f_CK', _i32), ('bf_d_CK', _i32), ('wbf_dcls', _f * 4), ('bf_c_CoutPad', _i32 * 4),
-                 ('bf_f_lanes', _i32), ('bf_d_lanes', _i32), ('f_ldsimg', _i32), ('d_ldsimg', _i32)])
+                 ('bf_f_lanes', _i32), ('bf_d_lanes', _i32), ('f_ldsimg', _i32), ('d_ldsimg', _i32),
+                 ('wdp_fwd', _f), ('wdp_dgrad', _f), ('wdp_dcls', _f * 4), ('wdp_scaled', _i32), ('wdp_rsv', _i32)])
 WLDS_WORDS = 2 * 2 * 9 * 32 * 36
 
 
@@ -100,6 +109,8 @@ _SIGS = {
     'sisr_conv2d_wgrad_f32': [C.POINTER(WgradDesc), _f],
     'sisr_conv2d_plan_bf16': [C.POINTER(ConvDesc)],
     'sisr_conv2d_bf16': [C.POINTER(ConvDesc), _f],
+    'sisr_conv2d_deep_plan': [C.POINTER(ConvDesc), _i32],
+    'sisr_conv2d_deep_eligible': [C.POINTER(ConvDesc)],
     'sisr_conv2d_trunk_eligible': [C.POINTER(ConvDesc)],
     'sisr_conv2d_bf16_parts': [C.POINTER(ConvDesc)],
     'sisr_conv2d_trunk_f32_eligible': [C.POINTER(ConvDesc)],
@@ -121,6 +132,9 @@ _SIGS = {
     'sisr_slab_reduce_f32': [_f, _f, _i32, _i64, _i64, _f],
     'sisr_wgrad_bf16_slab_lead': [C.POINTER(WgradDesc)],
     'sisr_weights_prepare': [_f, _i32, _i32, _i32, _f],
+    'sisr_weights_sn': [_f, _i32, _i32, _i32, _f],
+    'sisr_weights_pack': [_f, _i32, _i32, _i32, _f],
+    'sisr_weights_pack_deep': [_f, _i32, _i32, _i32, _f],
     'sisr_weights_grad': [_f, _i32, _f, _i32, _f],
     'sisr_weights_grad_tiles': [C.POINTER(WeightGradDesc)],
     'sisr_bn_finalize': [_f, _f, _i32, _i32, _f, _f, _f, _f, _f32, _f32, _f, _f, _f, _f, _f],
@@ -145,6 +159,10 @@ _SIGS = {
     'sisr_fc_dgrad': [_f, _f, _f, _f, _i32, _i32, _i32, _f],
     'sisr_fc_wgrad': [_f, _f, _f32, _f, _f, _i32, _i32, _i32, _f],
     'sisr_act_bwd': [_f, _f, _f, _i64, _i32, _f32, _f],
+    'sisr_fc_head_ws_floats': [_i32],
+    'sisr_fc_head_forward': [_f, _f, _f, _f, _f, _f32, _f, _f, _f, _i32, _i32, _i32, _f],
+    'sisr_fc_head_backward': [_f, _f, _f, _f, _f32, _f, _f, _f, _f, _i32, _i32, _f],
+    'sisr_fc1_dgrad': [_f, _f, _f, _i32, _i32, _i32, _f],
     'sisr_resize_coeffs': [_i32, _i32, _f, _f],
     'sisr_resize_u8_normalize': [_f, _f, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f, _i32, _f, _f, _i32, _f32, _f32, _f],
     'sisr_bicubic_fwd': [_f, _f, _i32, _i32, _i32, _i32, _i32, _i32, _f],
@@ -190,10 +208,10 @@ def lib():
     L.sisr_version.argtypes = []
     sizes = (_i32 * 8)()
     n = L.sisr_struct_sizes(sizes, 8)
-    mine = [C.sizeof(t) for t in (ConvDesc, WgradDesc, WeightDesc, WeightGradDesc, BnBwdDesc, ConvPlan)]
-    if n != 6 or list(sizes[:6]) != mine:
+    mine = [C.sizeof(t) for t in (ConvDesc, WgradDesc, WeightDesc, WeightGradDesc, BnBwdDesc, ConvPlan, DeepPlan)]
+    if n != 7 or list(sizes[:7]) != mine:
         raise RuntimeError('libsisr_hip.so does not match the Python mirror of sisr_hip.h: %s vs %s'
-                           % (list(sizes[:6]), mine))
+                           % (list(sizes[:7]), mine))
     _lib = L
     return L
 

@@ -641,9 +641,18 @@ extern "C" int sisr_conv2d_trunk_eligible(const SisrConvDesc* d);
 int sisr_conv2d_trunk_launch(const SisrConvDesc* d, hipStream_t st);            // conv_trunk.hip
 extern "C" int sisr_conv2d_toimage_eligible(const SisrConvDesc* d);
 int sisr_conv2d_toimage_launch(const SisrConvDesc* d, hipStream_t st);          // conv_toimage.hip
+extern "C" int sisr_conv2d_deep_eligible(const SisrConvDesc* d);
+int sisr_conv2d_deep_launch(const SisrConvDesc* d, hipStream_t st);             // conv_deep.hip
 
 extern "C" int sisr_conv2d_bf16(const SisrConvDesc* d, void* stream) {
-    if (!d || !d->x1 || !d->wpk || !d->y) return SISR_E_BADARG;
+    if (!d || !d->x1 || !d->y) return SISR_E_BADARG;
+    // the split-K implicit-GEMM family (conv_deep.hip): a descriptor planned for it carries that family's weight image and
+    // NOT the generic one, so it either runs there or is refused -- never silently on another kernel
+    if (d->deep.enabled && d->wdeep) {
+        if (!sisr_conv2d_deep_eligible(d)) return SISR_E_UNSUPPORTED;
+        return sisr_conv2d_deep_launch(d, reinterpret_cast<hipStream_t>(stream));
+    }
+    if (!d->wpk) return SISR_E_BADARG;
     if (operand_needs_x2(d->pro_mode) && !d->x2) return SISR_E_BADARG;
     if (d->stat_part && (!d->cnt_part || d->y_mode != SISR_Y_NHWC)) return SISR_E_BADARG;
     if (d->y_bf16 && (d->y_mode == SISR_Y_NCHW || (d->Cout & 7) || d->epi_act != SISR_EPI_NONE ||

@@ -974,8 +974,10 @@ extern "C" int sisr_conv2d_trunk_eligible(const SisrConvDesc* d) {
 
 // rows of stat_part / cnt_part (or bnb_part) a launch of this descriptor writes: the trunk kernel writes one per
 // workgroup, the generic kernels one per tile (plan.n_tiles)
+int sisr_conv2d_deep_parts(const SisrConvDesc* d);            // conv_deep.hip
 extern "C" int sisr_conv2d_bf16_parts(const SisrConvDesc* d) {
     if (!d) return SISR_E_BADARG;
+    if (d->deep.enabled && d->wdeep) return sisr_conv2d_deep_parts(d);
     if (sisr_conv2d_trunk_eligible(d)) return trunk_grid(d);
     return d->plan.n_tiles;
 }

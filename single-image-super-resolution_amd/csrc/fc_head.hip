@@ -1,0 +1,207 @@
+// fc_head.hip -- the discriminator's classifier head (model_discriminator.py:47-53):
+//     Linear(fc_in, 2 f) -> LeakyReLU -> Linear(2 f, 1) -> Sigmoid          fc_in = 18,432 (HR 96) / 73,728 (HR 192), 2 f = 1,024
+// forward and backward, as four kernels around the ONE tensor that matters -- W1 [1024][fc_in] fp32, 75 / 302 MB, streamed
+// exactly once per pass at 16 bytes per lane:
+//   fc1_forward_kernel   h1 partials = x W1^T on the exact-fp32 matrix instruction (v_mfma_f32_16x16x4_f32: rows = 16 weight rows,
+//                        columns = the 16 batch rows, one K = 4 step per dword of a lane's 16-byte loads).  The round-3 kernel did
+//                        these 604 MFLOP on the vector ALU (4,608 dependent-free but issue-bound FMAs per thread, one wave per
+//                        SIMD): 107 us for 75 MB.  Here a wave's arithmetic is 4 MFMAs per KB of weights (4 us of matrix pipe in
+//                        all) and the kernel is what it should be: a weight stream with 8 loads of 1 KB in flight per wave.
+//                        Workgroup = 16 weight rows x a quarter of K (4 waves x a sixteenth each), so 64 x 4 = 256 workgroups.
+//   fc_head_finish_kernel  sums the K quarters in order, adds b1, stores h1 (the backward needs the pre-activation), and runs
+//                        the whole second layer: out = sigmoid(lrelu(h1) . W2 + b2) -- one workgroup per batch row.
+//   fc_head_bwd_kernel   everything of the backward that is not W1-sized: d2 = g out (1 - out), dW2, db2, d1 = d2 W2 lrelu'(h1), db1.
+//   fc1_dgrad_kernel     dx = d1 W1 on the same instruction: workgroup = 64 columns of K, its 4 waves split the 1,024 rows and
+//                        meet in LDS (no global partials, fixed order); 4 weight rows x 256 contiguous bytes per load.
+// dW1 = d1^T x is an outer product with a 16-deep contraction: write-bound, it stays on the vector kernel of layout_fc.hip.
+// All sums are fp32 in a fixed order (deterministic); exact-fp32 products, so the same kernels serve the fp32 parity build
+// and the bf16 build (whose classifier head stays fp32: its tensors are 16 x 1,024).
+#include "sisr_dev.h"
+
+#include <algorithm>
+
+typedef float fcx4 __attribute__((ext_vector_type(4)));
+
+#define FH_B 16                      // batch rows of one call (the MFMA's 16 columns); rows >= B are zeros
+#define FH_KQ 4                      // K quarters (workgroups per 16-row group)
+#define FH_UNROLL 8                  // 16-byte loads in flight per lane and operand
+
+__device__ __forceinline__ fcx4 fh_mfma(float a, float b, fcx4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// x: [B][K] (already activated: in_slope applied here on load when != 1), W: [N][K]; part: [FH_KQ][FH_B][N]
+__global__ void __launch_bounds__(256) fc1_forward_kernel(const float* __restrict__ x, float in_slope, const float* __restrict__ W,
+                                                          float* __restrict__ part, int B, int K, int N) {
+    __shared__ float red[4][16 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16, kq = blockIdx.y;
+    const int li = lane & 15, kk = lane >> 4;
+    // K steps of 16 floats: step s covers k = 16 s + 4 kk + j for MFMA j (the same permutation of K on both operands)
+    const int steps = K >> 4, nsl = FH_KQ * 4, sl = kq * 4 + wave;
+    const int s0 = (int)((int64_t)steps * sl / nsl), s1 = (int)((int64_t)steps * (sl + 1) / nsl);
+    const float* wp = W + (int64_t)(n0 + li) * K + 4 * kk;
+    const float* xp = x + (int64_t)li * K + 4 * kk;
+    const bool xok = li < B;
+    fcx4 acc = {0.f, 0.f, 0.f, 0.f};
+    const fcx4 zero = {0.f, 0.f, 0.f, 0.f};
+    int s = s0;
+    for (; s + FH_UNROLL <= s1; s += FH_UNROLL) {
+        fcx4 wv[FH_UNROLL], xv[FH_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FH_UNROLL; ++u) {
+            wv[u] = __builtin_nontemporal_load(reinterpret_cast<const fcx4*>(wp + (int64_t)(s + u) * 16));
+            xv[u] = xok ? *reinterpret_cast<const fcx4*>(xp + (int64_t)(s + u) * 16) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < FH_UNROLL; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = fh_mfma(wv[u][j], lrelu(xv[u][j], in_slope), acc);
+    }
+    for (; s < s1; ++s) {
+        const fcx4 wv = *reinterpret_cast<const fcx4*>(wp + (int64_t)s * 16);
+        const fcx4 xv = xok ? *reinterpret_cast<const fcx4*>(xp + (int64_t)s * 16) : zero;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = fh_mfma(wv[j], lrelu(xv[j], in_slope), acc);
+    }
+    // acc[r]: weight row n0 + 4 kk + r, batch column li.  The 4 waves (K sixteenths of this quarter) meet in LDS, fixed order.
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(4 * kk + r) * 16 + li] = acc[r];
+    __syncthreads();
+    {
+        const int row = tid >> 4, b = tid & 15;
+        const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        part[((int64_t)kq * FH_B + b) * N + n0 + row] = v;
+    }
+}
+
+// one workgroup per batch row: h1[b][:] = sum of the K quarters + b1; out[b] = sigmoid(sum_n lrelu(h1[b][n], slope) W2[n] + b2)
+// (W2 == nullptr: first layer only)
+__global__ void __launch_bounds__(256) fc_head_finish_kernel(const float* __restrict__ part, const float* __restrict__ b1,
+                                                             float* __restrict__ h1, const float* __restrict__ W2,
+                                                             const float* __restrict__ b2, float slope, float* __restrict__ out,
+                                                             int N) {
+    __shared__ float scratch[8];
+    const int b = blockIdx.x;
+    float dot = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < FH_KQ; ++q) v += part[((int64_t)q * FH_B + b) * N + n];
+        v += b1 ? b1[n] : 0.f;
+        h1[(int64_t)b * N + n] = v;
+        if (W2) dot += lrelu(v, slope) * W2[n];
+    }
+    if (W2) {
+        const float t = block_sum(dot, scratch) + (b2 ? b2[0] : 0.f);
+        if (threadIdx.x == 0) out[b] = 1.f / (1.f + expf(-t));
+    }
+}
+
+// backward of everything behind h1 (thread = one of the N hidden units; B <= 16 batch rows looped):
+//   d2[b] = g[b] out[b] (1 - out[b]);  dW2[n] = sum_b d2[b] lrelu(h1[b][n]);  db2 = sum_b d2[b]
+//   d1[b][n] = d2[b] W2[n] (h1[b][n] > 0 ? 1 : slope);  db1[n] = sum_b d1[b][n]
+__global__ void __launch_bounds__(256) fc_head_bwd_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                          const float* __restrict__ h1, const float* __restrict__ W2, float slope,
+                                                          float* __restrict__ d1, float* __restrict__ dW2, float* __restrict__ db2,
+                                                          float* __restrict__ db1, int B, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    float d2[FH_B];
+    float sb2 = 0.f;
+#pragma unroll
+    for (int b = 0; b < FH_B; ++b) {
+        d2[b] = 0.f;
+        if (b < B) { const float o = out[b]; d2[b] = g[b] * o * (1.f - o); sb2 += d2[b]; }
+    }
+    if (n == 0 && db2) db2[0] = sb2;
+    if (n >= N) return;
+    const float w = W2[n];
+    float sw = 0.f, sb1 = 0.f;
+#pragma unroll
+    for (int b = 0; b < FH_B; ++b) {
+        if (b < B) {
+            const float h = h1[(int64_t)b * N + n];
+            sw += d2[b] * lrelu(h, slope);
+            const float dv = d2[b] * w * (h > 0.f ? 1.f : slope);
+            d1[(int64_t)b * N + n] = dv;
+            sb1 += dv;
+        }
+    }
+    dW2[n] = sw;
+    if (db1) db1[n] = sb1;
+}
+
+// dx[b][k] = sum_n d1[b][n] W[n][k].  MFMA j of a step: A[i = b][kk] = d1[b][n + kk], B[kk][jj] = W[n + kk][k0 + 4 jj + j]
+// (a lane's 16-byte load = 4 consecutive k of row n + kk): accumulator j holds columns k0 + 4 jj + j, jj = 0..15.
+__global__ void __launch_bounds__(256) fc1_dgrad_kernel(const float* __restrict__ d1, const float* __restrict__ W,
+                                                        float* __restrict__ dx, int B, int K, int N) {
+    __shared__ float red[4][FH_B * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k0 = blockIdx.x * 64;
+    const int li = lane & 15, kk = lane >> 4;
+    const int rows = N >> 2;                              // rows of this wave: [wave * rows, (wave + 1) * rows)
+    const int nb = wave * rows;
+    fcx4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = fcx4{0.f, 0.f, 0.f, 0.f};
+    const float* wp = W + (int64_t)(nb + kk) * K + k0 + 4 * li;
+    const bool bok = li < B;
+    for (int n = 0; n < rows; n += 4 * FH_UNROLL) {
+        fcx4 wv[FH_UNROLL];
+        float av[FH_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FH_UNROLL; ++u) {
+            const int r = n + 4 * u;
+            const bool ok = r + kk < rows;
+            wv[u] = ok ? __builtin_nontemporal_load(reinterpret_cast<const fcx4*>(wp + (int64_t)r * K)) : fcx4{0.f, 0.f, 0.f, 0.f};
+            av[u] = (ok && bok) ? d1[(int64_t)li * N + nb + r + kk] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < FH_UNROLL; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fh_mfma(av[u], wv[u][j], acc[j]);
+    }
+    // acc[j][r]: batch row 4 kk + r, column k0 + 4 li + j
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(4 * kk + r) * 64 + 4 * li + j] = acc[j][r];
+    __syncthreads();
+    for (int i = tid; i < FH_B * 64; i += 256) {
+        const int b = i >> 6, c = i & 63;
+        if (b < B && k0 + c < K) dx[(int64_t)b * K + k0 + c] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------------------
+#define S_(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int sisr_fc_head_ws_floats(int32_t N) { return FH_KQ * FH_B * N; }
+
+// forward of the whole head.  x [B][K] fp32 (activated), W1 [N][K], b1 [N], W2 [N] (Linear(N, 1).weight), b2 [1];
+// out: h1 [B][N] (pre-activation of the hidden layer), y [B] (sigmoid output); ws: sisr_fc_head_ws_floats(N) floats.
+extern "C" int sisr_fc_head_forward(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, float slope,
+                                    float* h1, float* y, float* ws, int32_t B, int32_t K, int32_t N, void* stream) {
+    if (!x || !W1 || !h1 || !ws || B <= 0 || B > FH_B || K <= 0 || (K & 15) || N <= 0 || (N & 15)) return SISR_E_BADARG;
+    if (W2 && !y) return SISR_E_BADARG;
+    hipLaunchKernelGGL(fc1_forward_kernel, dim3(N / 16, FH_KQ), dim3(256), 0, S_(stream), x, 1.f, W1, ws, B, K, N);
+    SISR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fc_head_finish_kernel, dim3(B), dim3(256), 0, S_(stream), ws, b1, h1, W2, b2, slope, y, N);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+// backward of the head behind h1: g [B] = dL/dy; -> d1 [B][N] = dL/dh1, dW2 [N], db2 [1], db1 [N]
+extern "C" int sisr_fc_head_backward(const float* g, const float* y, const float* h1, const float* W2, float slope, float* d1,
+                                     float* dW2, float* db2, float* db1, int32_t B, int32_t N, void* stream) {
+    if (!g || !y || !h1 || !W2 || !d1 || !dW2 || B <= 0 || B > FH_B || N <= 0) return SISR_E_BADARG;
+    hipLaunchKernelGGL(fc_head_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, S_(stream), g, y, h1, W2, slope, d1, dW2, db2, db1, B, N);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+// dx [B][K] = d1 [B][N] W1 [N][K]
+extern "C" int sisr_fc1_dgrad(const float* d1, const float* W1, float* dx, int32_t B, int32_t K, int32_t N, void* stream) {
+    if (!d1 || !W1 || !dx || B <= 0 || B > FH_B || K <= 0 || (K & 63) || N <= 0 || (N % (16 * FH_UNROLL))) return SISR_E_BADARG;
+    hipLaunchKernelGGL(fc1_dgrad_kernel, dim3(K / 64), dim3(256), 0, S_(stream), d1, W1, dx, B, K, N);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}

@@ -91,11 +91,11 @@ extern "C" int sisr_tr16_selftest(short* out_dev, void* stream) {
 }
 
 extern "C" int sisr_struct_sizes(int32_t* out, int32_t cap) {
-    const int32_t v[6] = {(int32_t)sizeof(SisrConvDesc), (int32_t)sizeof(SisrWgradDesc), (int32_t)sizeof(SisrWeightDesc),
+    const int32_t v[7] = {(int32_t)sizeof(SisrConvDesc), (int32_t)sizeof(SisrWgradDesc), (int32_t)sizeof(SisrWeightDesc),
                           (int32_t)sizeof(SisrWeightGradDesc), (int32_t)sizeof(SisrBnBwdDesc),
-                          (int32_t)sizeof(SisrConvPlan)};
-    for (int i = 0; i < 6 && i < cap; ++i) out[i] = v[i];
-    return 6;
+                          (int32_t)sizeof(SisrConvPlan), (int32_t)sizeof(SisrDeepPlan)};
+    for (int i = 0; i < 7 && i < cap; ++i) out[i] = v[i];
+    return 7;
 }
 
 // hipGetLastError() is per host thread and sticky until fetched: a failed stream capture (or any other failed
@@ -103,5 +103,5 @@ extern "C" int sisr_struct_sizes(int32_t* out, int32_t cap) {
 // would report it as its own.  Returns the error that was pending (0: none) and clears it.
 extern "C" int sisr_clear_last_error(void) { return (int)hipGetLastError(); }
 
-extern "C" const char* sisr_version(void) { return "sisr_hip 0.1 (gfx950, fp32 MFMA path)"; }
+extern "C" const char* sisr_version(void) { return "sisr_hip 0.4 (gfx950)"; }
 

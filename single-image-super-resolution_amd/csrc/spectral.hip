@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) sn_u_finish_kernel(const SisrWeigh
     const SisrWeightDesc w = table[blockIdx.x];
     const int tid = threadIdx.x;
     if (w.u == nullptr) {
-        if (tid == 0 && w.sigma) w.sigma[0] = 1.f;
+        if (tid == 0 && w.sigma) { w.sigma[0] = 1.f; w.sigma[1] = 1.f; }
         return;
     }
     const int rows = w.Cout, cols = w.Cin * w.KH * w.KW;
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) sn_u_finish_kernel(const SisrWeigh
         if (w.u_used) w.u_used[i] = u;
     }
     const float sigma = block_sum(part, scratch);
-    if (tid == 0 && w.sigma) w.sigma[0] = sigma;
+    if (tid == 0 && w.sigma) { w.sigma[0] = sigma; w.sigma[1] = 1.f / sigma; }      // [1]: the conv_deep.hip epilogue scale
 }
 
 // packed channel index -> original output channel (PixelShuffle(2) consumers use (i,j)-major order)
@@ -335,6 +335,59 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_kernel(const SisrWeig
     }
 }
 
+// conv_deep.hip images (SisrWeightDesc.wdp_*): [32-channel chunk][tap row][cout][KW * 32 + 8] bf16, element kx * 32 + ci, the 8
+// padding elements zero.  Workgroup = one 32 cout x 32 cin tile of a 3x3 weight: its 32 x 288 floats are read ONCE, as 32
+// contiguous 1,152-byte pieces (the generic pack kernel gathers every element with a 36-byte stride, once per image), pass
+// through LDS and leave as whole rows of every image that is asked for -- forward, data gradient (channels swapped, taps
+// flipped), the four output-parity classes of a stride-2 layer's data gradient.  grid (weights, cout chunks, cin chunks).
+__global__ void __launch_bounds__(SISR_BLOCK) weights_pack_deep_kernel(const SisrWeightDesc* table) {
+    __shared__ float tile[32][9 * 32 + 1];                         // [cout][ci * 9 + tap]
+    const SisrWeightDesc w = table[blockIdx.x];
+    if (w.wdp_fwd == nullptr && w.wdp_dgrad == nullptr && w.wdp_dcls[0] == nullptr && w.wdp_dcls[1] == nullptr &&
+        w.wdp_dcls[2] == nullptr && w.wdp_dcls[3] == nullptr)
+        return;
+    const int cb = blockIdx.y, kb = blockIdx.z;                    // cout chunk, cin chunk
+    if (cb * 32 >= w.Cout || kb * 32 >= w.Cin || w.KH != 3 || w.KW != 3) return;
+    const float sc = w.wdp_scaled ? 1.f / (w.sigma ? w.sigma[0] : 1.f) : 1.f;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 32 * 288; i += SISR_BLOCK) {
+        const int co = i / 288, e = i - co * 288;
+        tile[co][e] = w.w_orig[((int64_t)(cb * 32 + co) * w.Cin + kb * 32) * 9 + e] * sc;
+    }
+    __syncthreads();
+    const int RW = 3 * 32 + 8;
+    if (w.wdp_fwd) {
+        // rows (ky, co) of chunk kb: element kx * 32 + ci = tile[co][ci][ky][kx]
+        __bf16* dst = reinterpret_cast<__bf16*>(w.wdp_fwd);
+        for (int i = tid; i < 3 * 32 * RW; i += SISR_BLOCK) {
+            const int row = i / RW, k = i - row * RW, ky = row >> 5, co = row & 31;
+            const float v = k < 96 ? tile[co][(k & 31) * 9 + ky * 3 + (k >> 5)] : 0.f;
+            dst[((int64_t)(kb * 3 + ky) * w.Cout + cb * 32 + co) * RW + k] = (__bf16)v;
+        }
+    }
+    if (w.wdp_dgrad) {
+        // conv over dy: chunk = cb (over the forward couts), rows (ky', op = ci), element kx' * 32 + co = tile[co][ci][2 - ky'][2 - kx']
+        __bf16* dst = reinterpret_cast<__bf16*>(w.wdp_dgrad);
+        for (int i = tid; i < 3 * 32 * RW; i += SISR_BLOCK) {
+            const int row = i / RW, k = i - row * RW, ky = row >> 5, ci = row & 31;
+            const float v = k < 96 ? tile[k & 31][ci * 9 + (2 - ky) * 3 + (2 - (k >> 5))] : 0.f;
+            dst[((int64_t)(cb * 3 + ky) * w.Cin + kb * 32 + ci) * RW + k] = (__bf16)v;
+        }
+    }
+    for (int cls = 0; cls < 4; ++cls) {
+        __bf16* dst = reinterpret_cast<__bf16*>(w.wdp_dcls[cls]);
+        if (dst == nullptr) continue;
+        const int KHc = w.c_KH[cls], KWc = w.c_KW[cls], RWc = KWc * 32 + 8;
+        for (int i = tid; i < KHc * 32 * RWc; i += SISR_BLOCK) {
+            const int row = i / RWc, k = i - row * RWc, rp = row >> 5, ci = row & 31;
+            const int r = w.c_R0y[cls] - 2 * rp, sx = w.c_R0x[cls] - 2 * (k >> 5);
+            float v = 0.f;
+            if (k < KWc * 32 && r >= 0 && r < 3 && sx >= 0 && sx < 3) v = tile[k & 31][ci * 9 + r * 3 + sx];
+            dst[((int64_t)(cb * KHc + rp) * w.Cin + kb * 32 + ci) * RWc + k] = (__bf16)v;
+        }
+    }
+}
+
 // weight-gradient epilogue: the reduced packed gradient is a [K rows][CoutPad] matrix (K = chunk, tap, channel
 // in the conv kernels' order), the parameter gradient is OIHW -- a transpose with a row permutation.  A workgroup
 // takes one tile (32 packed couts x one channel chunk x all taps) through LDS: coalesced 128-byte reads along the
@@ -473,8 +526,9 @@ static int parts_for(int64_t elems) {           // workgroups per weight for the
     return (int)std::max<int64_t>(16, std::min<int64_t>(want, 1024));
 }
 
-extern "C" int sisr_weights_prepare(const SisrWeightDesc* table_dev, int32_t n, int32_t max_rows, int32_t max_cols,
-                                    void* stream) {
+// the three parts of sisr_weights_prepare as entry points of their own: a caller that keeps packed images across forwards
+// (W_orig does not change between two optimizer steps; only u, v, sigma do) runs the power iteration alone
+extern "C" int sisr_weights_sn(const SisrWeightDesc* table_dev, int32_t n, int32_t max_rows, int32_t max_cols, void* stream) {
     if (!table_dev || n <= 0 || max_rows <= 0 || max_cols <= 0) return SISR_E_BADARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int jobs_a = ((max_rows + SN_RB - 1) / SN_RB) * ((max_cols + SN_CB - 1) / SN_CB);
@@ -486,10 +540,31 @@ extern "C" int sisr_weights_prepare(const SisrWeightDesc* table_dev, int32_t n, 
     SISR_CHECK_LAUNCH();
     hipLaunchKernelGGL(sn_u_finish_kernel, dim3(n), dim3(SISR_BLOCK), 0, st, table_dev);
     SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_weights_pack(const SisrWeightDesc* table_dev, int32_t n, int32_t max_rows, int32_t max_cols, void* stream) {
+    if (!table_dev || n <= 0 || max_rows <= 0 || max_cols <= 0) return SISR_E_BADARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // packed images are a little larger than the matrix (padding slots): parts from 2x its size
     hipLaunchKernelGGL(weights_pack_kernel, dim3(n, parts_for(2ll * max_rows * max_cols)), dim3(SISR_BLOCK), 0, st, table_dev);
     SISR_CHECK_LAUNCH();
     return 0;
+}
+
+// the conv_deep.hip images (wdp_*) of every 3x3 weight of the table that asks for one; max_cout / max_cin over those weights
+extern "C" int sisr_weights_pack_deep(const SisrWeightDesc* table_dev, int32_t n, int32_t max_cout, int32_t max_cin, void* stream) {
+    if (!table_dev || n <= 0 || max_cout <= 0 || max_cin <= 0) return SISR_E_BADARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(weights_pack_deep_kernel, dim3(n, (max_cout + 31) / 32, (max_cin + 31) / 32), dim3(SISR_BLOCK), 0, st, table_dev);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_weights_prepare(const SisrWeightDesc* table_dev, int32_t n, int32_t max_rows, int32_t max_cols,
+                                    void* stream) {
+    if (int e = sisr_weights_sn(table_dev, n, max_rows, max_cols, stream)) return e;
+    return sisr_weights_pack(table_dev, n, max_rows, max_cols, stream);
 }
 
 // tiles (= workgroups along grid.y, = dot_work entries) one weight of the table needs; `parts` of sisr_weights_grad must

@@ -121,11 +121,31 @@ class Operand:
 class ConvGeom:
     """Static geometry of one convolution + cached kernel plans per input shape."""
 
-    def __init__(self, cin, cout, k, stride=1, pad=None, shuffle2=False):
+    def __init__(self, cin, cout, k, stride=1, pad=None, shuffle2=False, deep_dgrad=False):
         self.cin, self.cout, self.k, self.stride = cin, cout, k, stride
         self.pad = (k // 2) if pad is None else pad
         self.shuffle2 = shuffle2
+        # trunk-shaped layers (3x3, 64 -> 64, stride 1) whose DATA GRADIENT never arrives with a BatchNorm-backward prologue
+        # (the frozen VGG stack): the persistent trunk kernel refuses it, so it is planned for conv_deep.hip instead
+        self.deep_dgrad = deep_dgrad
         self._plans = {}
+
+    def _deep_ok(self, role, h, w):
+        """this role (0 forward, 1 data gradient) of the layer is planned for the split-K implicit-GEMM family (conv_deep.hip):
+        bf16 tensors, 3x3, channels in 32s / 64s, no PixelShuffle store; the trunk geometry stays with the persistent trunk
+        kernels wherever they take it (H % 8 == 0, W % 16 == 0)"""
+        if PRECISION != 'bf16' or not storage_bf16() or os.environ.get('SISR_DEEP', '1') == '0':
+            return False
+        if self.k != 3 or self.shuffle2:
+            return False
+        cin, cout = (self.cin, self.cout) if role == 0 else (self.cout, self.cin)
+        if cin % 32 or cout % 64:
+            return False
+        trunk_shape = (self.cin == 64 and self.cout == 64 and self.stride == 1 and h % 8 == 0 and w % 16 == 0
+                       and os.environ.get('SISR_TRUNK', '1') != '0')
+        if trunk_shape and not (role == 1 and self.deep_dgrad):
+            return False
+        return True
 
     def out_hw(self, h, w):
         return ((h + 2 * self.pad - self.k) // self.stride + 1, (w + 2 * self.pad - self.k) // self.stride + 1)
@@ -144,14 +164,16 @@ class ConvGeom:
         bf = PRECISION == 'bf16' and self.cout % 32 == 0 and lib.sisr_conv2d_plan_bf16(C.byref(d)) == 0
         if not bf:
             L.check(lib.sisr_conv2d_plan(C.byref(d)), 'sisr_conv2d_plan(dgrad stride-2 class)')
-        return (d, r0y, r0x, bool(bf))
+        elif self._deep_ok(1, h, w) and lib.sisr_conv2d_deep_plan(C.byref(d), 0) == 0:
+            bf = 2                                                    # conv_deep.hip
+        return (d, r0y, r0x, bf if bf == 2 else bool(bf))
 
     def plans(self, n, h, w, max_pixel_blocks=None):
         """-> (fwd desc, dgrad desc | [4 class descs] | None, wgrad desc, kinds) where kinds =
         (fwd_bf16, dgrad_bf16, wgrad_bf16) tells which kernel family each template was planned for."""
         if max_pixel_blocks is None:
             max_pixel_blocks = int(os.environ.get('SISR_WGRAD_PIXEL_BLOCKS', '512'))      # A/B knob of the wgrad grids
-        key = (n, h, w, PRECISION, storage_bf16(), max_pixel_blocks)
+        key = (n, h, w, PRECISION, storage_bf16(), max_pixel_blocks, os.environ.get('SISR_DEEP', '1'))
         if key in self._plans:
             return self._plans[key]
         lib = L.lib()
@@ -168,6 +190,8 @@ class ConvGeom:
         f_bf = want_bf16 and self.cin % 32 == 0 and lib.sisr_conv2d_plan_bf16(C.byref(f)) == 0
         if not f_bf:
             L.check(lib.sisr_conv2d_plan(C.byref(f)), 'sisr_conv2d_plan(fwd)')
+        elif self._deep_ok(0, h, w) and lib.sisr_conv2d_deep_plan(C.byref(f), 0) == 0:
+            f_bf = 2                                                  # kind 2: conv_deep.hip (its own weight image)
         d = None
         d_bf = False
         if self.stride == 1:
@@ -181,6 +205,8 @@ class ConvGeom:
             d_bf = want_bf16 and self.cout % 32 == 0 and lib.sisr_conv2d_plan_bf16(C.byref(d)) == 0
             if not d_bf:
                 L.check(lib.sisr_conv2d_plan(C.byref(d)), 'sisr_conv2d_plan(dgrad)')
+            elif self._deep_ok(1, h, w) and lib.sisr_conv2d_deep_plan(C.byref(d), 0) == 0:
+                d_bf = 2
         else:
             d = [self._s2_class_plan(lib, n, h, w, ho, wo, py, px) for py in (0, 1) for px in (0, 1)]
         g = L.WgradDesc()
@@ -197,7 +223,7 @@ class ConvGeom:
             g.Cout = self.cout
             L.check(lib.sisr_wgrad_plan(C.byref(g), max_pixel_blocks), 'sisr_wgrad_plan')
         g.slab_stride = g.slab_elems + g.CoutPad
-        self._plans[key] = (f, d, g, (bool(f_bf), bool(d_bf), bool(g_bf)))
+        self._plans[key] = (f, d, g, (f_bf if f_bf == 2 else bool(f_bf), d_bf if d_bf == 2 else bool(d_bf), bool(g_bf)))
         return self._plans[key]
 
 
@@ -219,7 +245,7 @@ class ConvRef:
 
 class Prepared:
     """Per-forward products of sisr_weights_prepare for one conv (kept for the backward pass)."""
-    __slots__ = ('ref', 'plans', 'kinds', 'wpk_fwd', 'wpk_dgrad', 'sigma', 'u_used', 'v_used', 'lanes', 'ldsimg')
+    __slots__ = ('ref', 'plans', 'kinds', 'wpk_fwd', 'wpk_dgrad', 'sigma', 'inv_sigma', 'u_used', 'v_used', 'lanes', 'ldsimg')
 
 
 def _trunk_ldsimg(gm, plan_f, plan_d, kinds):
@@ -236,40 +262,68 @@ def _trunk_ldsimg(gm, plan_f, plan_d, kinds):
 
 def _trunk_lanes(gm, plan_f, plan_d, kinds):
     """(forward, data-gradient): the bf16 weight buffer also gets the lane-order image of the persistent trunk kernels
-    (SisrWeightDesc.bf_f_lanes / bf_d_lanes) -- every 3x3 conv over 64 input channels whose packed couts come in blocks of 64"""
-    if os.environ.get('SISR_TRUNK_LANES', '1') == '0' or gm.k != 3:
+    (SisrWeightDesc.bf_f_lanes / bf_d_lanes) -- only where those kernels can take the layer: 3x3, stride 1, 64 input channels,
+    64 couts (or the 256 of the upscale conv) on the generic bf16 family (kind True, not the deep family's 2)"""
+    if os.environ.get('SISR_TRUNK_LANES', '1') == '0' or gm.k != 3 or gm.stride != 1:
         return False, False
-    lf = bool(kinds[0]) and gm.cin == 64 and plan_f.plan.CK == 32 and plan_f.plan.CoutPad % 64 == 0
-    ld = (bool(kinds[1]) and plan_d is not None and not isinstance(plan_d, list) and gm.cout == 64 and gm.cin == 64
+    lf = kinds[0] is True and gm.cin == 64 and plan_f.plan.CK == 32 and plan_f.plan.CoutPad in (64, 256)
+    ld = (kinds[1] is True and plan_d is not None and not isinstance(plan_d, list) and gm.cout == 64 and gm.cin == 64
           and plan_d.plan.CK == 32 and plan_d.plan.CoutPad == 64)
     return lf, ld
 
 
-def prepare_weights(items, training, need_dgrad=True):
-    """items: [(ConvRef, n, h, w)].  One multi-tensor launch: spectral-norm power iteration (in
-    place on u/v when training), sigma, and the packed W/sigma images for fwd and dgrad."""
+def _img_slots(desc, kind, lanes=False, ldsimg=0):
+    """fp32 slots of one packed weight image: kind 2 = conv_deep.hip's bf16 image, True = the generic bf16 image (twice with the
+    lane-order copy), False = the fp32 image (plus the LDS-order copy)"""
+    if kind == 2:
+        return (desc.deep.wimg_elems + 1) // 2
+    if kind:
+        return ((desc.plan.wpk_elems + 1) // 2) * (2 if lanes else 1)
+    return desc.plan.wpk_elems + (L.WLDS_WORDS if ldsimg else 0)
+
+
+_WEIGHT_EPOCH = [0]
+
+
+def invalidate_weight_caches():
+    """Packed weight images kept across forwards (prepare_weights(cache=...)) are valid only while the weights they were made from
+    are: anything that changes parameters WITHOUT torch's version counter noticing calls this -- the fused Adam step (its kernel
+    writes through raw pointers) and every HIP-graph capture / segment begin (an optimizer step the capture cannot see runs at
+    the boundary when the graph is replayed, and the cached buffer of another capture is that graph's private memory)."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+def prepare_weights(items, training, need_dgrad=True, cache=None):
+    """items: [(ConvRef, n, h, w)].  Spectral-norm power iteration (in place on u/v when training), sigma, and the packed images
+    for fwd and dgrad.  Images of the generic / trunk kernels hold W / sigma and are rebuilt on every call; the conv_deep.hip
+    images (kind 2) hold W_orig itself -- those kernels apply 1 / sigma in their epilogue (Prepared.inv_sigma) -- so with `cache`
+    (a dict owned by the module) they are packed once per optimizer step, not once per forward: the discriminator runs three
+    forwards per SRGAN iteration, two of them on unchanged weights (train.py:132,156,174)."""
     lib = L.lib()
     dev = items[0][0].weight.device
-    total, small = 0, 0
+    total, dtotal, small = 0, 0, 0
     metas = []
+
+    def alloc(desc, kind, lanes=False, ldsimg=0):
+        nonlocal total, dtotal
+        n_ = _align4(_img_slots(desc, kind, lanes, ldsimg))
+        if kind == 2:
+            off = ('d', dtotal, n_)
+            dtotal += n_
+        else:
+            off = ('b', total, n_)
+            total += n_
+        return off
     for ref, n, h, w in items:
         f, d, g, kinds = ref.geom.plans(n, h, w)
         lanes = _trunk_lanes(ref.geom, f, d, kinds)
         ldsimg = _trunk_ldsimg(ref.geom, f, d, kinds)
-        off_f = total
-        total += _align4(((f.plan.wpk_elems + 1) // 2) * (2 if lanes[0] else 1) if kinds[0]
-                         else f.plan.wpk_elems + (L.WLDS_WORDS if ldsimg[0] else 0))   # bf16: 2 per float slot
+        off_f = alloc(f, kinds[0], lanes[0], ldsimg[0])
         off_d = None
         if need_dgrad and isinstance(d, list):
-            off_d = []
-            for cls in d:
-                off_d.append(None if cls is None else total)
-                if cls is not None:
-                    total += _align4((cls[0].plan.wpk_elems + 1) // 2 if cls[3] else cls[0].plan.wpk_elems)
+            off_d = [None if cls is None else alloc(cls[0], cls[3]) for cls in d]
         elif need_dgrad and d is not None:
-            off_d = total
-            total += _align4(((d.plan.wpk_elems + 1) // 2) * (2 if lanes[1] else 1) if kinds[1]
-                             else d.plan.wpk_elems + (L.WLDS_WORDS if ldsimg[1] else 0))
+            off_d = alloc(d, kinds[1], lanes[1], ldsimg[1])
         off_s = small
         rows_, cols_ = ref.geom.cout, ref.geom.cin * ref.geom.k * ref.geom.k
         small += 4 + (_align4(rows_) + _align4(cols_) if ref.u is not None else 0)
@@ -278,9 +332,24 @@ def prepare_weights(items, training, need_dgrad=True):
         metas.append((off_f, off_d, off_s, off_w))
     big = torch.empty(total, dtype=torch.float32, device=dev)
     sm = torch.empty(small, dtype=torch.float32, device=dev)
+    deep_hit = False
+    deep = None
+    if dtotal:
+        key = (_WEIGHT_EPOCH[0], dtotal, need_dgrad, torch.cuda.is_current_stream_capturing(),
+               tuple((id(ref.weight), ref.weight.data_ptr(), ref.weight._version, n, h, w) for ref, n, h, w in items))
+        if cache is not None and cache.get('key') == key and os.environ.get('SISR_WCACHE', '1') != '0':
+            deep, deep_hit = cache['deep'], True
+        else:
+            deep = torch.empty(dtotal, dtype=torch.float32, device=dev)
+            if cache is not None:
+                cache['key'], cache['deep'] = key, deep
+
+    def view(off):
+        return None if off is None else (deep if off[0] == 'd' else big)[off[1]:off[1] + off[2]]
     table = (L.WeightDesc * len(items))()
     out = []
     max_rows = max_cols = 1
+    deep_cout = deep_cin = 0
     for i, ((ref, n, h, w), (off_f, off_d, off_s, off_w)) in enumerate(zip(items, metas)):
         f, d, g, kinds = ref.geom.plans(n, h, w)
         gm = ref.geom
@@ -288,27 +357,31 @@ def prepare_weights(items, training, need_dgrad=True):
         p.ref, p.plans, p.kinds = ref, (f, d, g), kinds
         p.lanes = _trunk_lanes(gm, f, d, kinds)
         p.ldsimg = _trunk_ldsimg(gm, f, d, kinds)
-        p.wpk_fwd = big[off_f:off_f + (((f.plan.wpk_elems + 1) // 2) * (2 if p.lanes[0] else 1) if kinds[0]
-                                      else f.plan.wpk_elems + (L.WLDS_WORDS if p.ldsimg[0] else 0))]
-        if isinstance(off_d, list):
-            p.wpk_dgrad = [None if o is None else
-                           big[o:o + ((cls[0].plan.wpk_elems + 1) // 2 if cls[3] else cls[0].plan.wpk_elems)]
-                           for o, cls in zip(off_d, d)]
-        else:
-            p.wpk_dgrad = (big[off_d:off_d + (((d.plan.wpk_elems + 1) // 2) * (2 if p.lanes[1] else 1) if kinds[1]
-                                             else d.plan.wpk_elems + (L.WLDS_WORDS if p.ldsimg[1] else 0))]
-                           if off_d is not None else None)
+        p.wpk_fwd = view(off_f)
+        p.wpk_dgrad = [view(o) for o in off_d] if isinstance(off_d, list) else view(off_d)
         p.sigma = sm[off_s:off_s + 1]
+        p.inv_sigma = sm[off_s + 1:off_s + 2]          # written next to sigma: the conv_deep.hip epilogue scale
         t = table[i]
         t.w_orig = ref.weight.data_ptr()
         t.sigma = p.sigma.data_ptr()
-        if kinds[0]:
+        t.wdp_scaled = 0
+        has_deep = False
+        if kinds[0] == 2:
+            has_deep = True
+            if not deep_hit:
+                t.wdp_fwd = p.wpk_fwd.data_ptr()
+        elif kinds[0]:
             t.wbf_fwd, t.bf_f_CoutPad, t.bf_f_CK = p.wpk_fwd.data_ptr(), f.plan.CoutPad, f.plan.CK
             t.bf_f_lanes = int(p.lanes[0])
         else:
             t.wpk_fwd = p.wpk_fwd.data_ptr()
             t.f_ldsimg = p.ldsimg[0]
-        if kinds[1]:
+        if kinds[1] == 2:
+            if off_d is not None:
+                has_deep = True
+                if not deep_hit:
+                    t.wdp_dgrad = p.wpk_dgrad.data_ptr()
+        elif kinds[1]:
             t.wbf_dgrad, t.bf_d_CoutPad, t.bf_d_CK = p.wpk_dgrad.data_ptr(), d.plan.CoutPad, d.plan.CK
             t.bf_d_lanes = int(p.lanes[1] and off_d is not None)
         else:
@@ -324,6 +397,11 @@ def prepare_weights(items, training, need_dgrad=True):
                     continue
                 cd, r0y, r0x, cbf = cls
                 t.c_KH[ci], t.c_KW[ci], t.c_R0y[ci], t.c_R0x[ci] = cd.KH, cd.KW, r0y, r0x
+                if cbf == 2:
+                    has_deep = True
+                    if not deep_hit:
+                        t.wdp_dcls[ci] = buf.data_ptr()
+                    continue
                 if cbf:
                     t.wbf_dcls[ci], t.bf_c_CoutPad[ci] = buf.data_ptr(), cd.plan.CoutPad
                     continue
@@ -333,6 +411,8 @@ def prepare_weights(items, training, need_dgrad=True):
         elif off_d is not None and not kinds[1]:
             t.d_CK, t.d_PS, t.d_KROWP, t.d_n_chunk, t.d_CoutPad = (d.plan.CK, d.plan.PS, d.plan.KROWP,
                                                                      d.plan.n_chunk, d.plan.CoutPad)
+        if has_deep:
+            deep_cout, deep_cin = max(deep_cout, gm.cout), max(deep_cin, gm.cin)
         p.u_used = p.v_used = None
         max_rows, max_cols = max(max_rows, gm.cout), max(max_cols, gm.cin * gm.k * gm.k)
         if ref.u is not None:
@@ -344,9 +424,15 @@ def prepare_weights(items, training, need_dgrad=True):
             t.u_used, t.v_used = p.u_used.data_ptr(), p.v_used.data_ptr()
         out.append(p)
     tab_dev = _table_to_device(table, dev)
-    L.check(lib.sisr_weights_prepare(tab_dev.data_ptr(), len(items), max_rows, max_cols, _stream()),
-            'sisr_weights_prepare')
-    return out, (big, sm, tab_dev)
+    any_sn = any(ref.u is not None for ref, _, _, _ in items)
+    # sigma must exist before any image that holds W / sigma is packed; weights without spectral norm get sigma = 1 from the
+    # finishing kernel of the power iteration (one workgroup per weight) -- skipped only when nothing but cached images is left
+    L.check(lib.sisr_weights_sn(tab_dev.data_ptr(), len(items), max_rows, max_cols, _stream()), 'sisr_weights_sn')
+    if total:
+        L.check(lib.sisr_weights_pack(tab_dev.data_ptr(), len(items), max_rows, max_cols, _stream()), 'sisr_weights_pack')
+    if dtotal and not deep_hit:
+        L.check(lib.sisr_weights_pack_deep(tab_dev.data_ptr(), len(items), deep_cout, deep_cin, _stream()), 'sisr_weights_pack_deep')
+    return out, (big, sm, tab_dev, deep)
 
 
 _PIN_RING = {'buf': None, 'off': 0, 'half': 0, 'events': [[], []], 'streams': {}}
@@ -426,6 +512,18 @@ def _table_to_device(table, dev):
     return host.to(dev, non_blocking=True)
 
 
+def _attach_deep(desc, image, dev, prep):
+    """descriptor planned for conv_deep.hip: hand it that family's weight image (instead of `wpk`), the 1 / sigma its epilogue
+    applies (the image holds W_orig) and a split workspace"""
+    desc.wdeep, desc.wpk = image.data_ptr(), None
+    desc.epi_scale_p = prep.inv_sigma.data_ptr()
+    ws = None
+    if desc.deep.ws_bytes > 0:
+        ws = torch.empty((desc.deep.ws_bytes // 4,), dtype=torch.float32, device=dev)
+        desc.deep_ws = ws.data_ptr()
+    return ws
+
+
 def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, res=None, out=None):
     """Launch the forward conv of `prep` on lazy operand `op`.  Returns (y, stat_part, cnt_part)."""
     lib = L.lib()
@@ -448,6 +546,7 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
     f.wpk, f.bias, f.res, f.y = prep.wpk_fwd.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr()
     f.y_bf16, f.res_bf16 = _bf(out), _bf(res)
     f.epi_act = epi
+    ws = _attach_deep(f, prep.wpk_fwd, dev, prep) if prep.kinds[0] == 2 else None          # (kept alive until the launch below)
     f.mfma_split = mfma_split()
     f.plan.variant = int(prep.lanes[0]) | (2 * prep.ldsimg[0])           # bit 0: lane-order bf16 image; bits 1-2: LDS-order fp32 image (mode)
     fin = op.fin
@@ -455,6 +554,7 @@ def conv_forward(prep, op, bias=None, y_mode=None, epi=L.EPI_NONE, stats=False, 
         # deferred BatchNorm finalisation: by this conv when it runs on a persistent trunk kernel, else stand-alone first
         fin.fill(f)
         if os.environ.get('SISR_FUSE_BNFIN', '1') != '0' and \
+                prep.kinds[0] != 2 and \
                 (lib.sisr_conv2d_trunk_eligible if prep.kinds[0] else lib.sisr_conv2d_trunk_f32_eligible)(C.byref(f)) == 1:
             fin.done = True
         else:
@@ -496,8 +596,12 @@ def can_fuse_bn_backward(prep):
     """the data-gradient conv of `prep` can also emit the backward reductions of the BatchNorm its output feeds
     (generic bf16 kernel, one cout tile)"""
     d = prep.plans[1]
-    if isinstance(d, list) or d is None:
+    if isinstance(d, list):                       # stride 2: the four parity classes, all on the deep family
+        return all(c is not None and c[3] == 2 for c in d)
+    if d is None:
         return False
+    if prep.kinds[1] == 2:                        # conv_deep.hip: any number of cout tiles
+        return True
     if not prep.kinds[1]:
         # fp32 build: only the persistent trunk kernel (conv_trunk_f32.hip) has that epilogue; conv_dgrad() falls back
         # to the plain launch (and returns no partial rows) when the filled descriptor turns out not to be eligible
@@ -505,6 +609,16 @@ def can_fuse_bn_backward(prep):
         return (gm.cin == 64 and gm.cout == 64 and gm.k == 3 and gm.stride == 1 and d.H % 8 == 0 and d.W % 16 == 0
                 and os.environ.get('SISR_TRUNK', '1') != '0' and os.environ.get('SISR_TRUNK_F32CONV', '1') != '0')
     return d.plan.variant == 0 and d.plan.CoutPad == d.plan.nsub * 32
+
+
+def _fill_bnb(d, consts, slope):
+    d.bnb_scale, d.bnb_shift, d.bnb_mean, d.bnb_invstd = (consts[0].data_ptr(), consts[1].data_ptr(),
+                                                          consts[2].data_ptr(), consts[3].data_ptr())
+    d.bnb_act = 0 if slope is None else 1
+    if isinstance(slope, torch.Tensor):
+        d.bnb_slope_p, d.bnb_slope = slope.data_ptr(), 1.0
+    else:
+        d.bnb_slope_p, d.bnb_slope = None, 1.0 if slope is None else float(slope)
 
 
 def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
@@ -519,6 +633,9 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
         assert y_mode == L.Y_NHWC
         complete = all(c is not None for c in prep.plans[1])
         out = (torch.empty if complete else torch.zeros)((f.N, f.H, f.W, gm.cin), dtype=act_dtype(gm.cin), device=dev)
+        # fused BatchNorm-backward reductions: every class of the deep family emits the partial rows of ITS quarter of the pixels
+        fuse = bnb is not None and all(c is not None and c[3] == 2 for c in prep.plans[1])
+        descs = []
         for cls, buf in zip(prep.plans[1], prep.wpk_dgrad):
             if cls is None:
                 continue
@@ -527,11 +644,28 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
             dy_op.fill(d)
             d.wpk, d.bias, d.res, d.y = buf.data_ptr(), None, _ptr(res), out.data_ptr()
             d.y_bf16, d.res_bf16 = _bf(out), _bf(res)
-            if cls[3]:
+            ws = _attach_deep(d, buf, dev, prep) if cls[3] == 2 else None
+            descs.append((d, cls[3], ws))
+        part = None
+        if fuse:
+            x, consts, slope = bnb
+            assert tuple(x.shape) == tuple(out.shape)
+            rows = []
+            for d, _, _ in descs:
+                d.bnb_x, d.bnbx_bf16, d.bnb_part = x.data_ptr(), _bf(x), d.y
+                rows.append(lib.sisr_conv2d_bf16_parts(C.byref(d)))
+            part = torch.empty((sum(rows), 2 * gm.cin + 1), dtype=torch.float32, device=dev)
+            r0 = 0
+            for (d, _, _), nr in zip(descs, rows):
+                d.bnb_part = part[r0:].data_ptr()
+                r0 += nr
+                _fill_bnb(d, consts, slope)
+        for d, kind, ws in descs:
+            if kind:
                 L.check(lib.sisr_conv2d_bf16(C.byref(d), _stream()), 'sisr_conv2d_bf16(dgrad s2)')
             else:
                 L.check(lib.sisr_conv2d_f32(C.byref(d), _stream()), 'sisr_conv2d_f32(dgrad s2)')
-        return out
+        return out if bnb is None else (out, part)
     d = _copy_struct(prep.plans[1])
     assert tuple(dy_op.dims) == (d.N, d.H, d.W, d.Cin), (dy_op.dims, (d.N, d.H, d.W, d.Cin))
     dev = dy_op.x1.device
@@ -544,6 +678,7 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
     d.wpk, d.bias, d.res, d.y = prep.wpk_dgrad.data_ptr(), None, _ptr(res), out.data_ptr()
     d.y_bf16, d.res_bf16 = _bf(out), _bf(res)
     d.mfma_split = mfma_split()
+    ws = _attach_deep(d, prep.wpk_dgrad, dev, prep) if prep.kinds[1] == 2 else None        # (kept alive until the launch below)
     d.plan.variant = int(prep.lanes[1]) | (2 * prep.ldsimg[1])
     part = None
     if bnb is not None:
@@ -555,13 +690,7 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
         if rows > 0:
             part = torch.empty((rows, 2 * gm.cin + 1), dtype=torch.float32, device=dev)
             d.bnb_part = part.data_ptr()
-            d.bnb_scale, d.bnb_shift, d.bnb_mean, d.bnb_invstd = (consts[0].data_ptr(), consts[1].data_ptr(),
-                                                                  consts[2].data_ptr(), consts[3].data_ptr())
-            d.bnb_act = 0 if slope is None else 1
-            if isinstance(slope, torch.Tensor):
-                d.bnb_slope_p, d.bnb_slope = slope.data_ptr(), 1.0
-            else:
-                d.bnb_slope_p, d.bnb_slope = None, 1.0 if slope is None else float(slope)
+            _fill_bnb(d, consts, slope)
         else:                                        # fp32 build, descriptor not taken by the persistent kernel: no fusion
             d.bnb_x, d.bnb_part = None, None
     if prep.kinds[1]:
@@ -864,6 +993,55 @@ def fc_backward(dy, x, w, in_slope=1.0, need_dx=True):
             L.check(lib.sisr_fc_dgrad(dyc.data_ptr(), w.data_ptr(), dx[b0:b0 + nb].data_ptr(), work.data_ptr(), nb, k, nout,
                                       _stream()), 'sisr_fc_dgrad')
     return dx, dw, db
+
+
+def fc_head_ok(bsz, k, n):
+    """the classifier head of D runs on fc_head.hip (exact-fp32 MFMA weight streaming): up to 16 batch rows, K in 64s, N in 128s"""
+    return bsz <= FC_MAX_BATCH and k % 64 == 0 and n % 128 == 0 and os.environ.get('SISR_FC_HEAD', '1') != '0'
+
+
+def fc_head_forward(x, w1, b1, w2, b2, slope):
+    """-> (h1 [B, N] pre-activation, y [B, 1]) of Linear -> LeakyReLU -> Linear(N, 1) -> Sigmoid"""
+    lib = L.lib()
+    bsz, k = x.shape
+    n = w1.shape[0]
+    h1 = torch.empty((bsz, n), dtype=torch.float32, device=x.device)
+    y = torch.empty((bsz, 1), dtype=torch.float32, device=x.device)
+    ws = torch.empty((lib.sisr_fc_head_ws_floats(n),), dtype=torch.float32, device=x.device)
+    L.check(lib.sisr_fc_head_forward(x.data_ptr(), w1.data_ptr(), _ptr(b1), w2.data_ptr(), _ptr(b2), slope, h1.data_ptr(),
+                                     y.data_ptr(), ws.data_ptr(), bsz, k, n, _stream()), 'sisr_fc_head_forward')
+    return h1, y
+
+
+def fc_head_backward(g, y, h1, w2, slope):
+    """-> (d1 [B, N], dW2 like w2, db2 [1], db1 [N])"""
+    lib = L.lib()
+    bsz, n = h1.shape
+    dev = h1.device
+    d1 = torch.empty_like(h1)
+    dw2 = torch.empty_like(w2)
+    db2 = torch.empty((1,), dtype=torch.float32, device=dev)
+    db1 = torch.empty((n,), dtype=torch.float32, device=dev)
+    L.check(lib.sisr_fc_head_backward(g.data_ptr(), y.data_ptr(), h1.data_ptr(), w2.data_ptr(), slope, d1.data_ptr(),
+                                      dw2.data_ptr(), db2.data_ptr(), db1.data_ptr(), bsz, n, _stream()), 'sisr_fc_head_backward')
+    return d1, dw2, db2, db1
+
+
+def fc1_dgrad(d1, w1):
+    bsz, n = d1.shape
+    k = w1.shape[1]
+    dx = torch.empty((bsz, k), dtype=torch.float32, device=d1.device)
+    L.check(L.lib().sisr_fc1_dgrad(d1.data_ptr(), w1.data_ptr(), dx.data_ptr(), bsz, k, n, _stream()), 'sisr_fc1_dgrad')
+    return dx
+
+
+def fc_wgrad_only(dy, x, w, in_slope=1.0):
+    """dW = dy^T lrelu(x) (no bias gradient, no data gradient)"""
+    bsz, k = x.shape
+    dw = torch.empty_like(w)
+    L.check(L.lib().sisr_fc_wgrad(dy.data_ptr(), x.data_ptr(), in_slope, dw.data_ptr(), None, bsz, k, w.shape[0], _stream()),
+            'sisr_fc_wgrad')
+    return dw
 
 
 def act_bwd(dy, ref, kind, slope=0.0):

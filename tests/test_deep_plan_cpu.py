@@ -1,0 +1,155 @@
+"""Host logic of the split-K implicit-GEMM family (csrc/conv_deep.hip): the planner's tiling and the tile -> memory maps the
+kernel derives from it, replayed in numpy against torch's convolution on the CPU (no GPU, no kernel launch).
+
+The kernel's index arithmetic is restated here line by line (deep_tile, rbase, the staging map, a_base, row_off), so a plan that
+would make the kernel read a wrong pixel -- a band of rows straddling images, a stride-2 halo, an output-parity class of a stride-2
+data gradient -- fails here before it ever reaches the GPU box."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+L = importlib.import_module('single-image-super-resolution_amd._lib')
+
+
+def _plan(n, h, w, cin, cout, kh, kw, stride, pad, ho, wo, y=(1, 0, 1, 0, None, None)):
+    d = L.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, cin, ho, wo, cout
+    d.KH, d.KW, d.stride, d.pad_y, d.pad_x = kh, kw, stride, pad, pad
+    d.y_sy, d.y_oy, d.y_sx, d.y_ox = y[:4]
+    d.y_H, d.y_W = y[4] or ho, y[5] or wo
+    rc = L.lib().sisr_conv2d_deep_plan(C.byref(d), 0)
+    return rc, d
+
+
+def _replay(d, x, wgt):
+    """out[n, oy, ox, co] computed through the kernel's maps: halo image in padded-row space, fragment bases, tap offsets"""
+    p = d.deep
+    S, KH, KW = d.stride, d.KH, d.KW
+    N, H, W, Ho, Wo = d.N, d.H, d.W, d.Ho, d.Wo
+    NQ = N * Ho
+    out = np.zeros((N, d.y_H, d.y_W, d.Cout), np.float64)
+    written = np.zeros((N, d.y_H, d.y_W), np.int32)
+
+    def rbase(q):
+        n = q // Ho
+        return n * p.PR + (q - n * Ho) * S
+    for mt in range(p.tiles_x * p.tiles_q):
+        tq, tx = divmod(mt, p.tiles_x)
+        q0, ox0 = tq * p.TH, tx * p.TW
+        qlast = min(q0 + p.TH, NQ) - 1
+        pb0 = rbase(q0)
+        IH = rbase(qlast) - pb0 + KH
+        assert IH <= p.IH_max, (IH, p.IH_max)
+        IW = p.IW
+        npix = IH * IW
+        assert (npix * 4 + 255) // 256 <= p.NIT
+        halo = np.zeros((p.IH_max * IW, d.Cin), np.float64)
+        ix0 = ox0 * S - d.pad_x
+        for pix in range(npix):
+            hr, hc = divmod(pix, IW)
+            prow = pb0 + hr
+            n = prow // p.PR
+            iy = prow - n * p.PR - d.pad_y
+            ix = ix0 + hc
+            if n < N and 0 <= iy < H and 0 <= ix < W:
+                halo[pix] = x[n, iy, ix]
+        for m in range(128):
+            r, c = divmod(m, p.TW)
+            q, ox = q0 + r, ox0 + c
+            if not (r < p.TH and q < NQ and ox < Wo):
+                continue
+            base = (rbase(q) - pb0) * IW + c * S
+            acc = np.zeros(d.Cout)
+            for ky in range(KH):
+                for kx in range(KW):
+                    acc += halo[base + ky * IW + kx] @ wgt[:, :, ky, kx].T
+            n, oy = divmod(q, Ho)
+            py, px = oy * d.y_sy + d.y_oy, ox * d.y_sx + d.y_ox
+            out[n, py, px] = acc
+            written[n, py, px] += 1
+    return out, written
+
+
+CASES = [
+    # n, h, w, cin, cout, stride   (3x3, pad 1): D's shapes at HR 96 / 192, VGG's, the trunk at LR 24
+    (3, 12, 12, 32, 64, 1), (5, 6, 6, 32, 64, 1), (2, 24, 24, 32, 64, 1), (2, 48, 48, 32, 64, 1), (1, 16, 32, 32, 64, 1),
+    (3, 12, 12, 32, 64, 2), (3, 24, 24, 32, 64, 2), (2, 48, 48, 32, 64, 2), (1, 96, 96, 32, 64, 2), (2, 10, 14, 32, 64, 1),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_forward_maps_reproduce_conv2d(case):
+    n, h, w, cin, cout, st = case
+    ho, wo = (h + 2 - 3) // st + 1, (w + 2 - 3) // st + 1
+    rc, d = _plan(n, h, w, cin, cout, 3, 3, st, 1, ho, wo)
+    assert rc == 0 and d.deep.enabled == 1
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((n, h, w, cin))
+    wgt = rng.standard_normal((cout, cin, 3, 3))
+    out, written = _replay(d, x, wgt)
+    ref = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(wgt), stride=st, padding=1).permute(0, 2, 3, 1).numpy()
+    assert (written == 1).all()                              # the tiles partition the output
+    np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize('hw', [(12, 12), (24, 24), (96, 96), (6, 6)])
+def test_stride2_data_gradient_classes_reproduce_conv_transpose(hw):
+    """the four output-parity classes engine.ConvGeom plans for a stride-2 layer's data gradient, through the same maps"""
+    E = importlib.import_module('single-image-super-resolution_amd.engine')
+    h, w = hw
+    n, cin, cout = 2, 64, 32                                  # forward: cin -> cout; the gradient conv maps cout -> cin
+    ho, wo = h // 2, w // 2
+    rng = np.random.default_rng(1)
+    dy = rng.standard_normal((n, ho, wo, cout))
+    wgt = rng.standard_normal((cout, cin, 3, 3))
+    dx = np.zeros((n, h, w, cin))
+    cover = np.zeros((n, h, w), np.int32)
+    for py in (0, 1):
+        for px in (0, 1):
+            khc, pady, r0y = E._s2_taps(3, 1, py)
+            kwc, padx, r0x = E._s2_taps(3, 1, px)
+            hc, wc = (h - py + 1) // 2, (w - px + 1) // 2
+            assert pady == padx == 0
+            d = L.ConvDesc()
+            d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, ho, wo, cout, hc, wc, cin
+            d.KH, d.KW, d.stride, d.pad_y, d.pad_x = khc, kwc, 1, pady, padx
+            d.y_sy = d.y_sx = 2
+            d.y_oy, d.y_ox, d.y_H, d.y_W = py, px, h, w
+            assert L.lib().sisr_conv2d_deep_plan(C.byref(d), 0) == 0
+            # class weights as weights_pack_kernel builds them: tap (r', s') = forward tap (R0y - 2 r', R0x - 2 s'), channels swapped
+            wc_ = np.zeros((cin, cout, khc, kwc))
+            for rp in range(khc):
+                for sp in range(kwc):
+                    wc_[:, :, rp, sp] = wgt[:, :, r0y - 2 * rp, r0x - 2 * sp].T
+            o, wr = _replay(d, dy, wc_)
+            dx += o
+            cover += wr
+    ref = F.conv_transpose2d(torch.from_numpy(dy).permute(0, 3, 1, 2), torch.from_numpy(wgt), stride=2, padding=1,
+                             output_padding=1).permute(0, 2, 3, 1).numpy()
+    assert (cover == 1).all()
+    np.testing.assert_allclose(dx, ref, rtol=1e-9, atol=1e-9)
+
+
+def test_k_split_fills_the_chip_on_the_deepest_layers():
+    """D's 512 -> 512 stride-2 layer at B16 / HR 96 (576 output pixels) must not run as a handful of workgroups"""
+    rc, d = _plan(16, 12, 12, 512, 512, 3, 3, 2, 1, 6, 6)
+    p = d.deep
+    assert rc == 0 and p.split > 1 and p.split * p.cps >= p.n_chunk
+    assert p.tiles_x * p.tiles_q * p.n_ntiles * p.split >= 128
+    assert p.ws_bytes == p.tiles_x * p.tiles_q * p.n_ntiles * p.split * 128 * p.BN * 4
+    rc, d = _plan(16, 48, 48, 64, 128, 3, 3, 1, 1, 48, 48)       # plenty of pixel tiles: no split, no workspace
+    assert rc == 0 and d.deep.split == 1 and d.deep.ws_bytes == 0
+
+
+def test_unsupported_geometries_are_refused():
+    assert _plan(2, 12, 12, 3, 64, 3, 3, 1, 1, 12, 12)[0] != 0       # 3 input channels
+    assert _plan(2, 12, 12, 32, 3, 3, 3, 1, 1, 12, 12)[0] != 0       # 3 output channels
+    assert _plan(2, 12, 100, 32, 64, 3, 3, 1, 1, 12, 100)[0] != 0    # wide rows that are no multiple of the 8 x 16 tile
