@@ -25,6 +25,7 @@ class Topology:
         self.blocks = []         # (ConvRef, bn module)
         self.fc1 = None          # nn.Linear holders
         self.fc2 = None
+        self.cache = None        # dict owned by the module: packed conv_deep.hip images kept between optimizer steps
 
     def conv_refs(self):
         return [self.conv0] + [b[0] for b in self.blocks]
@@ -43,7 +44,7 @@ def run_forward(topo, x, training):
     for ref in refs:
         items.append((ref, n, hh, ww))
         hh, ww = ref.geom.out_hw(hh, ww)
-    preps, keep = E.prepare_weights(items, training)
+    preps, keep = E.prepare_weights(items, training, cache=topo.cache)
     P = {id(r): p for r, p in zip(refs, preps)}
     sv = Saved()
     sv.topo, sv.P, sv.keep, sv.x, sv.training = topo, P, keep, x, training

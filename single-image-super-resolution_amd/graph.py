@@ -157,6 +157,8 @@ class GraphedStep:
         torch.autograd.backward(_Call.apply(x, on_thread), g)
 
     def _begin(self):
+        from . import engine as E
+        E.invalidate_weight_caches()         # images packed before this point are another graph's memory or predate an optimizer step
         g = torch.cuda.CUDAGraph()
         g.capture_begin(pool=self._pool)
         self.graphs.append(g)

@@ -52,6 +52,7 @@ class Discriminator(nn.Module):
         t.conv0 = ConvRef(self.conv[0])
         t.blocks = [(ConvRef(b.layers[0]), b.layers[1]) for b in self.conv[2]]
         t.fc1, t.fc2 = self.fc[0], self.fc[2]
+        t.cache = self.__dict__.setdefault('_sisr_wcache', {})
         return t
 
     def forward(self, x):

@@ -43,6 +43,7 @@ class Adam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         lib = L.lib()
+        E.invalidate_weight_caches()      # the kernel below rewrites parameters behind torch's version counters
         for gi, group in enumerate(self.param_groups):
             by_step = {}
             for p in group['params']:

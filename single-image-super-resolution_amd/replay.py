@@ -6,7 +6,7 @@ by default on the CPU (config.py:49-54): every D step moves the current fake bat
 (train.py:144-156) and stores / overwrites one entry (train.py:66-71).  With 288 GB of HBM per MI355X the list
 lives where it is used: ``DeviceReplayList`` is a drop-in for that list -- ``len()``, indexing, assignment,
 ``append`` and iteration as train.py uses them -- whose entries are views into ONE preallocated device ring
-(1000 batches of 16x3x96x96 fp32 = 1.8 GB; 7.1 GB at 192x192), so storing a batch is one device copy and
+(1000 + 1 batches of 16x3x96x96 fp32 = 1.8 GB; 7.1 GB at 192x192), so storing a batch is one device copy and
 presenting it costs nothing.  Set ``dis_list_old_cpu = False`` (config.py:53) and build the list with
 ``gen_dis_list`` below instead of config.py:323-331; train.py itself is unchanged.
 
@@ -15,13 +15,17 @@ reference (``numpy.random.choice`` / ``random.randint``), so a seeded run picks 
 
 Two properties of the reference's plain list that the ring must not lose:
 
-* **Assignment rebinds, it never mutates.**  train.py runs the D forwards on the sampled entries (train.py:64), THEN
-  assigns ``dis_list_old[randint] = curr_fake`` (train.py:68-69), THEN calls ``errD.backward()`` (train.py:74).  The
-  discriminator's backward reads its saved inputs, so copying into a ring slot at assignment time would hand the
-  weight gradient of the first conv the NEW batch whenever the overwritten slot was one of those just sampled.  An
-  assignment into a held slot is therefore only RECORDED; the device copy happens at the next READ access of the list
-  (sample / index / iterate / append / save), i.e. in the next iteration, after the backward pass that may still read
-  the old contents.  ``flush()`` forces it.
+* **Assignment rebinds, it never mutates -- and it snapshots.**  train.py runs the D forwards on the sampled entries
+  (train.py:64), THEN assigns ``dis_list_old[randint] = curr_fake`` (train.py:68-69), THEN calls ``errD.backward()``
+  (train.py:74).  The discriminator's backward reads its saved inputs, so writing into the ring row of the assigned slot
+  would hand the weight gradient of the first conv the NEW batch whenever that slot was one of those just sampled.  And the
+  assigned tensor may be a HIP graph's static output buffer (``graph.GraphedStep`` returns the same tensors on every replay), so
+  merely keeping a reference until later would store the NEXT iteration's fake.  The ring therefore has one row more than its
+  capacity: an assignment copies the batch into the spare row at once (stream-ordered behind the forwards already issued),
+  points the slot at that row, and the row the slot had -- which a pending backward may still read -- is quarantined until the
+  next read access of the list (sample / index / iterate / append / save: the next iteration) before it becomes the spare.
+  A second assignment before that read access finds no spare row and keeps a private CLONE of the batch, copied in at the
+  read access (``flush()`` forces both).
 * **The checkpoint holds a plain list.**  utils.py:108-115 pickles the object it was given as ``'dis_list'``;
   ``__reduce__`` makes that a Python list of the held batches as CPU tensors -- the reference's own format, readable
   without this package (``torch.load(..., weights_only=True)`` additionally needs
@@ -38,16 +42,25 @@ class DeviceReplayList:
 
     def __init__(self, capacity, device=None, dtype=torch.float32):
         self.capacity, self.device, self.dtype = int(capacity), device, dtype
-        self._ring = None             # allocated at the first append (the batch shape is not known before)
+        self._ring = None             # [capacity + 1, *batch_shape], allocated at the first append (shape unknown before)
         self._n = 0
-        self._pending = {}            # slot -> batch: assignments recorded but not copied yet (see module docstring)
+        self._map = list(range(self.capacity))      # slot -> ring row
+        self._spare = [self.capacity]               # free ring rows
+        self._quarantine = []                       # rows released by an assignment since the last read access
+        self._pending = {}            # slot -> private clone: assignments that found no spare row (see module docstring)
 
     def flush(self):
-        """apply the recorded assignments (one device copy each)"""
+        """read-access point: rows released by earlier assignments become spare, cloned assignments are copied in"""
         if self._pending:
             todo, self._pending = self._pending, {}
             for i, batch in todo.items():
-                self._ring[i].copy_(batch, non_blocking=True)
+                self._ring[self._map[i]].copy_(batch, non_blocking=True)
+        if self._quarantine:
+            self._spare += self._quarantine
+            self._quarantine = []
+
+    def _row(self, k):
+        return self._ring[self._map[k]]
 
     # ---- list protocol (what train.py:66-71,144-156 and utils.py:114 use) ------------------------------------------
     def __len__(self):
@@ -62,17 +75,24 @@ class DeviceReplayList:
     def __getitem__(self, i):
         self.flush()
         if isinstance(i, slice):
-            return [self._ring[k] for k in range(*i.indices(self._n))]
-        return self._ring[self._index(i)]
+            return [self._row(k) for k in range(*i.indices(self._n))]
+        return self._row(self._index(i))
 
     def __setitem__(self, i, batch):
         i = self._index(i)
         self._check_shape(batch)
-        self._pending[i] = batch.detach()              # (a second assignment to the same slot replaces the first)
+        if self._spare:
+            r = self._spare.pop()
+            self._ring[r].copy_(batch.detach(), non_blocking=True)     # snapshot NOW: the caller's buffer may be a graph's static output
+            self._quarantine.append(self._map[i])                       # the old row may still be read by a pending backward
+            self._map[i] = r
+            self._pending.pop(i, None)
+        else:
+            self._pending[i] = batch.detach().clone()                   # (a second assignment to the same slot replaces the first)
 
     def __iter__(self):
         self.flush()
-        return (self._ring[k] for k in range(self._n))
+        return (self._row(k) for k in range(self._n))
 
     def _check_shape(self, batch):
         if self._ring is not None and tuple(batch.shape) != tuple(self._ring.shape[1:]):
@@ -81,12 +101,12 @@ class DeviceReplayList:
     def append(self, batch):
         if self._ring is None:
             dev = self.device if self.device is not None else batch.device
-            self._ring = torch.empty((self.capacity,) + tuple(batch.shape), dtype=self.dtype, device=dev)
+            self._ring = torch.empty((self.capacity + 1,) + tuple(batch.shape), dtype=self.dtype, device=dev)
         self._check_shape(batch)
         if self._n == self.capacity:
             raise IndexError('replay list is full (%d entries): overwrite an entry instead (train.py:68-69)' % self.capacity)
         self.flush()
-        self._ring[self._n].copy_(batch, non_blocking=True)      # (a slot nobody has seen yet: nothing can be reading it)
+        self._row(self._n).copy_(batch, non_blocking=True)       # (a slot nobody has seen yet: nothing can be reading it)
         self._n += 1
 
     # ---- the reference's policies ------------------------------------------------------------------------------------
@@ -94,7 +114,7 @@ class DeviceReplayList:
         """train.py:144-145: ``int(len * ratio)`` distinct entries, drawn with numpy's global generator"""
         self.flush()
         idx = np.random.choice(list(range(self._n)), int(self._n * ratio), replace=False)
-        return [self._ring[int(i)] for i in idx]
+        return [self._row(int(i)) for i in idx]
 
     def store(self, batch, step, freq=1):
         """train.py:66-71: every ``freq`` steps keep the batch; once full, overwrite a random entry"""
@@ -109,7 +129,7 @@ class DeviceReplayList:
     def to_list(self):
         self.flush()
         # (own storage per entry: a view of a host-resident ring would drag the whole ring into torch.save)
-        return [self._ring[k].detach().to('cpu', copy=True) for k in range(self._n)]
+        return [self._row(k).detach().to('cpu', copy=True) for k in range(self._n)]
 
     def __reduce__(self):
         """pickled (torch.save of utils.py:108-115) as a plain list of the held batches on the CPU: the reference's own

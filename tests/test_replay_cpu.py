@@ -29,10 +29,11 @@ def test_store_and_overwrite_policy_matches_the_reference_list():
         lst.store(b, step, freq=2)
     assert len(lst) == len(ref) == 3
     assert all(torch.equal(a, b) for a, b in zip(lst, ref))
-    base = lst._ring.data_ptr()
-    assert [e.data_ptr() for e in lst] == [base + k * bs[0].numel() * 4 for k in range(3)]     # views of one ring
-    lst[1] = bs[0]                                                   # list assignment = (deferred) device copy into the slot
-    assert torch.equal(lst[1], bs[0]) and lst[1].data_ptr() == base + bs[0].numel() * 4
+    base, row = lst._ring.data_ptr(), bs[0].numel() * 4
+    ptrs = [e.data_ptr() for e in lst]
+    assert sorted(ptrs) == sorted(set(ptrs)) and all((q - base) % row == 0 and 0 <= (q - base) // row <= 3 for q in ptrs)   # distinct rows of ONE ring (capacity + the spare)
+    lst[1] = bs[0]                                                   # list assignment = one device copy into the spare row, slot re-pointed
+    assert torch.equal(lst[1], bs[0]) and (lst[1].data_ptr() - base) % row == 0
     assert torch.equal(lst[-1], ref[-1])
 
 
@@ -59,11 +60,13 @@ def test_checkpoint_round_trip_and_size_rule():
     assert len(R.gen_dis_list(saved, 5, 'cpu', progressive_gan_suffix=1)) == 0       # config.py:325-330: size changed
 
 
-def test_assignment_does_not_touch_a_sampled_entry_until_the_next_access():
+def test_assignment_does_not_touch_a_sampled_entry_and_snapshots_the_batch():
     """train.py:64-74: D forward on the sampled entries, THEN `dis_list_old[k] = curr_fake`, THEN backward.  The
-    reference's assignment rebinds the list entry and leaves the tensor autograd saved alone; the ring must do the same:
-    the sampled view keeps its contents until the list is accessed again (the next iteration)."""
-    bs = _batches(4)
+    reference's assignment rebinds the list entry and leaves the tensor autograd saved alone; the ring does the same by
+    pointing the slot at its spare row: the sampled view keeps its contents, the slot shows the new batch -- and that batch is
+    a COPY taken at assignment time, because the assigned tensor may be a HIP graph's static output buffer that the next replay
+    overwrites before the list is read again (graph.GraphedStep.__call__ returns the same tensors every time)."""
+    bs = _batches(6)
     lst = R.DeviceReplayList(3, device='cpu')
     for b in bs[:3]:
         lst.append(b)
@@ -71,14 +74,22 @@ def test_assignment_does_not_touch_a_sampled_entry_until_the_next_access():
     sampled = lst.sample(1.0)                                        # views of all three slots, as D's forward sees them
     before = [t.clone() for t in sampled]
     order = [int(i) for i in np.random.RandomState(1).choice(list(range(3)), 3, replace=False)]
-    lst[order[0]] = bs[3]                                            # overwrite a slot that was just sampled
-    assert all(torch.equal(a, b) for a, b in zip(sampled, before))  # ... the saved input of the pending backward is intact
-    assert torch.equal(lst[order[0]], bs[3])                         # next access: the new batch is there (list semantics)
-    assert torch.equal(sampled[0], bs[3])                            # (and the old view now shows it: same storage)
-    # two assignments in a row: the first is applied when the second is recorded
+    static_out = bs[3].clone()                                       # stands for a graphed step's static output tensor
+    lst[order[0]] = static_out                                       # overwrite a slot that was just sampled
+    static_out.copy_(bs[4])                                          # the next replay rewrites the buffer ...
+    assert all(torch.equal(a, b) for a, b in zip(sampled, before))  # the saved input of the pending backward is intact
+    assert torch.equal(lst[order[0]], bs[3])                         # ... and the list holds what was assigned, not what came later
+    assert all(torch.equal(a, b) for a, b in zip(sampled, before))  # (still intact after the read access: it is another row)
+    # two assignments before a read access: the second finds no spare row and keeps a private clone until the access
+    kept = lst.sample(1.0)
+    kept_before = [t.clone() for t in kept]
+    src = bs[5].clone()
     lst[0] = bs[1]
-    lst[1] = bs[0]
-    assert torch.equal(lst[0], bs[1]) and torch.equal(lst[1], bs[0])
+    lst[1] = src
+    src.zero_()
+    assert all(torch.equal(a, b) for a, b in zip(kept, kept_before))
+    assert torch.equal(lst[0], bs[1]) and torch.equal(lst[1], bs[5])
+    assert len(lst) == 3 and sorted(lst._map[:3] + lst._spare + lst._quarantine) == [0, 1, 2, 3]     # no row lost or doubled
     # shape mismatch is refused at assignment time, not at flush time
     try:
         lst[0] = torch.zeros(1, 3, 4, 4)
