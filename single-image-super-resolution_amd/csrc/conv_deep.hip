@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(DP_THREADS, NSUB == 2 ? 1 : 2) conv_deep_kerne
     const int npix = IH * IW;
     const int in_bytes = (p.IH_max * IW * DP_PSB + 15) & ~15;
     unsigned char* in_buf = lds;                                   // [2][in_bytes]
-    unsigned char* w_buf = lds + 2 * in_bytes;                     // [2][WSTAGE]
+    unsigned char* w_buf = lds + 2 * in_bytes;                     // [3][WSTAGE]: ring of weight stages
 
     // ---- staging map of this thread: item e = tid + 256 u = (halo pixel e >> 2, channel octet e & 3) -------------------------
     unsigned goff[NITM];
@@ -442,17 +442,19 @@ __global__ void __launch_bounds__(DP_THREADS, NSUB == 2 ? 1 : 2) conv_deep_kerne
     auto issue_in = [&](int chunk) { deep_issue_in<NITM, TWO>(r1, r2, goff, chunk, sa, sb); };
     auto commit = [&](int chunk, unsigned char* buf) { deep_commit<NITM, TWO>(d, pro, chunk, buf, loff0, okm, npix, slope, sa, sb); };
     // one weight stage, LDS-direct: the stage is a contiguous WSTAGE-byte block of the image; wave w lays down pieces w, w + 4, ..
+    // -- PW pieces per wave, no branch around a load (a wave whose last piece index runs past the stage lays the LAST piece down
+    // again: the same bytes to the same place as the wave that owns it), so every wave's vmcnt arithmetic is the same
+    constexpr int PW = (WPIECES + 3) / 4;
     const unsigned wlane = (unsigned)lane * 16u;
-    auto issue_w = [&](int chunk, int ky, unsigned char* buf) {
-        const unsigned so = (unsigned)(((chunk * KH + ky) * d.Cout + nt * BN) * WRB);
+    auto stage_so = [&](int chunk, int ky) { return (unsigned)(((chunk * KH + ky) * d.Cout + nt * BN) * WRB); };
+    auto issue_piece = [&](int k, unsigned so, unsigned char* buf) {
+        const int piece = min(wave + 4 * k, WPIECES - 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16,
+                                                 wlane + (unsigned)(piece * 1024), so, 0, 0);
+    };
+    auto issue_w = [&](unsigned so, unsigned char* buf) {
 #pragma unroll
-        for (int k = 0; k < (WPIECES + 3) / 4; ++k) {
-            // (no branch around a load: a wave whose last piece index runs past the stage lays the LAST piece down again --
-            // the same bytes to the same place as the wave that owns it)
-            const int piece = min(wave + 4 * k, WPIECES - 1);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16,
-                                                     wlane + (unsigned)(piece * 1024), so, 0, 0);
-        }
+        for (int k = 0; k < PW; ++k) issue_piece(k, so, buf);
     };
 
     // ---- fragment addresses ---------------------------------------------------------------------------------------------------
@@ -477,8 +479,12 @@ __global__ void __launch_bounds__(DP_THREADS, NSUB == 2 ? 1 : 2) conv_deep_kerne
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ms][ns][i] = 0.f;
 
-    // the MFMAs of one stage: KW taps x two K = 16 steps; the fragments of step s + 1 are requested before the MFMAs of step s
-    auto mma_stage = [&](const unsigned char* ain, const unsigned char* wb) {
+    // the MFMAs of one stage: KW taps x two K = 16 steps; the fragments of step s + 1 are requested before the MFMAs of step s.
+    // DMA: the LDS-direct pieces of the stage after next are issued BETWEEN the steps (an LDS-direct load costs the wave ~60-100
+    // issue cycles: in front of the MFMAs, as a block, those cycles were half of a stage; behind an MFMA group they are hidden)
+    auto mma_stage = [&](const unsigned char* ain, const unsigned char* wb, auto dma_c, unsigned so_next, unsigned char* buf_next) {
+        constexpr bool DMA = decltype(dma_c)::value;
+        constexpr int STEPS = 2 * KW;
         bf16x8 fa[2][2], fb[2][NSUB];
         auto fetch = [&](int step, int buf) {
             const int kx = step >> 1, k2 = step & 1;
@@ -489,10 +495,15 @@ __global__ void __launch_bounds__(DP_THREADS, NSUB == 2 ? 1 : 2) conv_deep_kerne
         };
         fetch(0, 0);
 #pragma unroll
-        for (int step = 0; step < 2 * KW; ++step) {
-            // pinned order: the NEXT step's fragment reads, then THIS step's MFMAs (left to itself the scheduler sinks every read
-            // to just before its use and the LDS latency is paid once per pair of MFMAs)
-            if (step + 1 < 2 * KW) fetch(step + 1, (step + 1) & 1);
+        for (int step = 0; step < STEPS; ++step) {
+            // pinned order: the NEXT step's fragment reads (+ this step's share of the DMA pieces), then THIS step's MFMAs
+            // (left to itself the scheduler sinks every read to just before its use: LDS latency once per pair of MFMAs)
+            if (step + 1 < STEPS) fetch(step + 1, (step + 1) & 1);
+            if constexpr (DMA) {
+#pragma unroll
+                for (int k = 0; k < PW; ++k)
+                    if (k * STEPS / PW == step) issue_piece(k, so_next, buf_next);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ms = 0; ms < 2; ++ms)
@@ -501,30 +512,50 @@ __global__ void __launch_bounds__(DP_THREADS, NSUB == 2 ? 1 : 2) conv_deep_kerne
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // wait until all but the wave's `N` youngest vector-memory operations are done, and every LDS operation; then the workgroup
+    // barrier.  NOT __syncthreads(): its fence would wait for vmcnt(0) and drain the LDS-direct loads that are meant to stay in flight
+#define DP_WAIT_BARRIER(N)                                                                                                        \
+    do {                                                                                                                           \
+        asm volatile("" ::: "memory");                                                                                             \
+        __builtin_amdgcn_s_waitcnt((((N) & 15) | 0x70 | (((N) >> 4) << 14)));                                                      \
+        __builtin_amdgcn_s_barrier();                                                                                              \
+        asm volatile("" ::: "memory");                                                                                             \
+    } while (0)
 
-    // ---- K loop over this slice's chunks: stage = (chunk, tap row) ------------------------------------------------------------
+    // ---- K loop over this slice's chunks: stage s = (chunk, tap row); weight ring of 3 stages: the pieces of stage s + 2 are issued
+    // during the MFMAs of stage s and have all of stage s + 1 to land; the halo of chunk c + 1 is requested at the first tap row of
+    // chunk c and committed at its last one.  A wave's vector-memory operations retire in issue order, so "stage s + 1 has landed"
+    // is "all but the operations issued after its last piece are done": the pieces of stage s + 2 and this stage's halo loads.
     const int c_begin = slice * p.cps, c_end = min(p.n_chunk, c_begin + p.cps);
+    const int nst = (c_end - c_begin) * KH;
+    constexpr int NIN = NITM * (TWO ? 2 : 1);
+    auto so_of = [&](int st) { const int c = st / KH; return stage_so(c_begin + c, st - c * KH); };
     issue_in(c_begin);
-    issue_w(c_begin, 0, w_buf);
+    issue_w(so_of(0), w_buf);
+    if (nst > 1) issue_w(so_of(1), w_buf + WSTAGE);
     commit(c_begin, in_buf);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): this wave's LDS-direct pieces have landed
-    __syncthreads();
+    if (nst > 1) DP_WAIT_BARRIER(PW); else DP_WAIT_BARRIER(0);      // stage 0 landed (stage 1 may still be in flight)
     int sidx = 0;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         const int ib = (chunk - c_begin) & 1;
         const bool more = chunk + 1 < c_end;
         for (int ky = 0; ky < KH; ++ky, ++sidx) {
             const bool last_row = ky == KH - 1;
-            // the next stage's weights go out first: they have this stage's MFMAs to land
-            if (!last_row) issue_w(chunk, ky + 1, w_buf + ((sidx + 1) & 1) * WSTAGE);
-            else if (more) issue_w(chunk + 1, 0, w_buf + ((sidx + 1) & 1) * WSTAGE);
-            if (ky == 0 && more) issue_in(chunk + 1);
-            mma_stage(in_buf + ib * in_bytes + ky * IW * DP_PSB, w_buf + (sidx & 1) * WSTAGE);
+            const bool in_now = ky == 0 && more, dma_now = sidx + 2 < nst;
+            if (in_now) issue_in(chunk + 1);
+            const unsigned char* ain = in_buf + ib * in_bytes + ky * IW * DP_PSB;
+            const unsigned char* wb = w_buf + (sidx % 3) * WSTAGE;
+            if (dma_now) mma_stage(ain, wb, std::true_type{}, so_of(sidx + 2), w_buf + ((sidx + 2) % 3) * WSTAGE);
+            else mma_stage(ain, wb, std::false_type{}, 0u, w_buf);
             if (last_row && more) commit(chunk + 1, in_buf + (ib ^ 1) * in_bytes);
-            __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): the next stage's weights (issued a stage ago) have landed
-            __syncthreads();
+            if (sidx + 1 >= nst) DP_WAIT_BARRIER(0);                // last stage: nothing may be in flight when the epilogue reuses LDS
+            else if (dma_now && in_now) DP_WAIT_BARRIER(PW + NIN);
+            else if (dma_now) DP_WAIT_BARRIER(PW);
+            else if (in_now) DP_WAIT_BARRIER(NIN);
+            else DP_WAIT_BARRIER(0);
         }
     }
+#undef DP_WAIT_BARRIER
 
     if (p.split > 1) {
         float* ws = d.deep_ws + deep_ws_index<NSUB>(p, mt, nt, slice);
@@ -560,16 +591,29 @@ __global__ void __launch_bounds__(DP_THREADS, NSUB == 2 ? 1 : 2) conv_deep_finis
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ms][ns][i] = 0.f;
     const float* ws = d.deep_ws + deep_ws_index<NSUB>(p, mt, nt, 0);
-    for (int z = 0; z < p.split; ++z, ws += DP_BM * NSUB * 64) {
+    constexpr int SLICE = DP_BM * NSUB * 64;
+    // slices in groups of four: every load of a group is in flight before the first add (the sum keeps slice order)
+    for (int z0 = 0; z0 < p.split; z0 += 4) {
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
             for (int ns = 0; ns < NSUB; ++ns)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(ws + ((((wave * 2 + ms) * NSUB + ns) * 4 + g) * 64 + lane) * 4);
+                    const int off = ((((wave * 2 + ms) * NSUB + ns) * 4 + g) * 64 + lane) * 4;
+                    f32x4 v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[ms][ns][4 * g + j] += v[j];
+                    for (int u = 0; u < 4; ++u) {
+                        // (slices past the last repeat it with weight 0: no branch around a load)
+                        const int z = min(z0 + u, p.split - 1);
+                        v[u] = *reinterpret_cast<const f32x4*>(ws + (int64_t)z * SLICE + off);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float wgt = z0 + u < p.split ? 1.f : 0.f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[ms][ns][4 * g + j] += wgt * v[u][j];
+                    }
                 }
     }
     deep_epilogue<NSUB>(d, acc, lds, mt, nt);
@@ -614,6 +658,11 @@ extern "C" int sisr_conv2d_deep_plan(SisrConvDesc* d, int32_t target_wg) {
     p.IH_max = (p.TH - 1) * S + d->KH + nb * (p.PR - d->Ho * S);
     p.NIT = (p.IH_max * p.IW * 4 + DP_THREADS - 1) / DP_THREADS;
     if (p.NIT > 10) return SISR_E_UNSUPPORTED;
+    {   // two halo buffers + a ring of three weight stages must fit the CU's 160 KB: the large halos of stride 2 take 64-cout tiles
+        const int in_bytes = (p.IH_max * p.IW * DP_PSB + 15) & ~15, wrb = d->KW * 64 + 16;
+        if (2 * in_bytes + 3 * p.BN * wrb > 160 * 1024 && p.BN == 128) { p.BN = 64; p.n_ntiles = d->Cout / 64; }
+        if (2 * in_bytes + 3 * p.BN * wrb > 160 * 1024) return SISR_E_UNSUPPORTED;
+    }
     if ((int64_t)d->N * p.PR >= 65536 || p.IH_max * p.IW >= 65536) return SISR_E_TOOBIG;
     // K split: reach ~target workgroups, at least two chunks per slice (a slice pays a prologue, an epilogue-sized partial
     // store and its share of the finishing pass)
@@ -639,7 +688,7 @@ extern "C" int sisr_conv2d_deep_plan(SisrConvDesc* d, int32_t target_wg) {
 static int deep_main_lds(const SisrConvDesc* d, int KW) {
     const SisrDeepPlan& p = d->deep;
     const int in_bytes = (p.IH_max * p.IW * DP_PSB + 15) & ~15;
-    return 2 * in_bytes + 2 * p.BN * (KW * 64 + 16);
+    return 2 * in_bytes + 3 * p.BN * (KW * 64 + 16);
 }
 
 template <int NSUB, int KW, int NITM, bool TWO>
