@@ -88,7 +88,7 @@ typedef struct SisrDeepPlan {
     int32_t IW, IH_max;             /* halo tile: columns, most rows of any tile                            */
     int32_t NIT;                    /* 16-byte staging items per thread                                     */
     int32_t wimg_elems;             /* bf16 elements of the weight image [chunk][tap row][Cout][KW*32 + 8]  */
-    int32_t rsv;
+    int32_t classes;                /* 1, or 4: the output-parity classes of a stride-2 data gradient in ONE launch   */
     int64_t ws_bytes;               /* bytes of the split workspace (0 when split == 1)                     */
     uint32_t m_tiles_x, m_tw, m_ho, m_pr, m_iw;
     uint32_t rsv2;
@@ -150,6 +150,14 @@ typedef struct SisrConvDesc {
     const void *wdeep;
     float *deep_ws;
     const float *epi_scale_p;
+    /* deep.classes == 4 -- the data gradient of a stride-2 3x3 convolution (even H, W) as ONE launch over its four output-parity
+     * classes c = 2 py + px: the descriptor describes the class convolution with the MOST taps (KH = KW = 2, stride 1, pad 0, over
+     * dy; Ho x Wo = the class grid H/2 x W/2; y_sy = y_sx = 2, y_H x y_W = the gradient's size); class c has deep_ckh[c] tap rows,
+     * writes output pixel (2 a + py, 2 b + px) and reads its weights from wdeep_c[c] -- always in the KW = 2 row format, a class
+     * with one tap per row carries zeros for the second (SisrWeightDesc.wdp_cls_kw = 2).  Partial rows (bnb_part) and split
+     * workspace tiles are class-major. */
+    const void *wdeep_c[4];
+    int32_t deep_ckh[4];
     SisrDeepPlan deep;
 } SisrConvDesc;
 
@@ -194,9 +202,12 @@ int sisr_conv2d_plan_bf16(SisrConvDesc *d);
 int sisr_conv2d_bf16(const SisrConvDesc *d, void *stream);
 /* conv_deep.hip: fills d->deep for a descriptor whose geometry / modes are set (after sisr_conv2d_plan_bf16); returns
  * SISR_E_UNSUPPORTED (and leaves deep.enabled = 0) for geometries that family does not take: Cin % 32, Cout % 64, taps <= 3 x 3,
- * stride 1 | 2, NHWC bf16 in and out.  target_wg: workgroups a launch should reach through the K split (0: default 256).
+ * stride 1 | 2, NHWC bf16 in and out.  target_wg: workgroup slots a launch should fill through the K split (0: default 256).
  * sisr_conv2d_bf16 dispatches to it when deep.enabled && wdeep; sisr_conv2d_bf16_parts counts its partial rows. */
-int sisr_conv2d_deep_plan(SisrConvDesc *d, int32_t target_wg);
+int sisr_conv2d_deep_plan(SisrConvDesc *d, int32_t target_wg, int32_t prefer_bn, int32_t classes);
+/* prefer_bn: 0 = choose (64-cout tiles, two workgroups per CU, where there are plenty of pixel tiles; 128 otherwise), 64 | 128 = a
+ * caller that knows its prologue is heavy (the two-tensor BatchNorm-backward forms cost ~500 vector instructions per chunk and
+ * thread: a 128-cout tile has twice the MFMAs to hide them behind) asks for 128.  classes: 1, or 4 (see SisrConvDesc.wdeep_c). */
 /* a fully filled descriptor (storage flags, modes, fusions, wdeep, deep_ws) will run on conv_deep.hip */
 int sisr_conv2d_deep_eligible(const SisrConvDesc *d);
 /* The generator's trunk geometry (3x3, 64 -> 64, stride 1, bf16 NHWC in and out, H % 8 == 0, W % 16 == 0; forward-type
@@ -303,7 +314,8 @@ typedef struct SisrWeightDesc {
      * W_orig itself (the kernels then apply 1 / sigma in their epilogue: SisrConvDesc.epi_scale_p), 1 packs W_orig / sigma */
     void *wdp_fwd, *wdp_dgrad;
     void *wdp_dcls[4];
-    int32_t wdp_scaled, wdp_rsv;
+    int32_t wdp_scaled;
+    int32_t wdp_cls_kw;       /* 0: a class image has c_KW taps per row; 2: every class image is written in the KW = 2 row format */
 } SisrWeightDesc;
 #define SISR_WLDS_WORDS (2 * 2 * 9 * 32 * 36)
 

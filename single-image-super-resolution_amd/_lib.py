@@ -32,7 +32,7 @@ class ConvPlan(C.Structure):
 
 class DeepPlan(C.Structure):
     _fields_ = ([(n, _i32) for n in ('enabled', 'TH', 'TW', 'tiles_x', 'tiles_q', 'BN', 'n_ntiles', 'n_chunk', 'split', 'cps',
-                                     'PR', 'IW', 'IH_max', 'NIT', 'wimg_elems', 'rsv')] +
+                                     'PR', 'IW', 'IH_max', 'NIT', 'wimg_elems', 'classes')] +
                 [('ws_bytes', _i64)] +
                 [(n, C.c_uint32) for n in ('m_tiles_x', 'm_tw', 'm_ho', 'm_pr', 'm_iw', 'rsv2')])
 
@@ -50,7 +50,7 @@ class ConvDesc(C.Structure):
                 [(n, _i32) for n in ('x_bf16', 'y_bf16', 'res_bf16', 'bnbx_bf16')] +
                 [('fin_rows', _i32), ('fin_momentum', _f32), ('fin_eps', _f32), ('mfma_split', _i32)] +
                 [('plan', ConvPlan)] +
-                [('wdeep', _f), ('deep_ws', _f), ('epi_scale_p', _f), ('deep', DeepPlan)])
+                [('wdeep', _f), ('deep_ws', _f), ('epi_scale_p', _f), ('wdeep_c', _f * 4), ('deep_ckh', _i32 * 4), ('deep', DeepPlan)])
 
 
 class WgradDesc(C.Structure):
@@ -80,7 +80,7 @@ class WeightDesc(C.Structure):
                 [('wbf_fwd', _f), ('wbf_dgrad', _f), ('bf_f_CoutPad', _i32), ('bf_d_CoutPad', _i32),
                  ('bf_f_CK', _i32), ('bf_d_CK', _i32), ('wbf_dcls', _f * 4), ('bf_c_CoutPad', _i32 * 4),
                  ('bf_f_lanes', _i32), ('bf_d_lanes', _i32), ('f_ldsimg', _i32), ('d_ldsimg', _i32),
-                 ('wdp_fwd', _f), ('wdp_dgrad', _f), ('wdp_dcls', _f * 4), ('wdp_scaled', _i32), ('wdp_rsv', _i32)])
+                 ('wdp_fwd', _f), ('wdp_dgrad', _f), ('wdp_dcls', _f * 4), ('wdp_scaled', _i32), ('wdp_cls_kw', _i32)])
 WLDS_WORDS = 2 * 2 * 9 * 32 * 36
 
 
@@ -109,7 +109,7 @@ _SIGS = {
     'sisr_conv2d_wgrad_f32': [C.POINTER(WgradDesc), _f],
     'sisr_conv2d_plan_bf16': [C.POINTER(ConvDesc)],
     'sisr_conv2d_bf16': [C.POINTER(ConvDesc), _f],
-    'sisr_conv2d_deep_plan': [C.POINTER(ConvDesc), _i32],
+    'sisr_conv2d_deep_plan': [C.POINTER(ConvDesc), _i32, _i32, _i32],
     'sisr_conv2d_deep_eligible': [C.POINTER(ConvDesc)],
     'sisr_conv2d_trunk_eligible': [C.POINTER(ConvDesc)],
     'sisr_conv2d_bf16_parts': [C.POINTER(ConvDesc)],

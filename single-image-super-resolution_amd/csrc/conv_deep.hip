@@ -146,6 +146,20 @@ __device__ __forceinline__ DeepTile deep_tile(const SisrConvDesc& d, int mt) {
     return t;
 }
 
+// output-parity classes (SisrConvDesc.wdeep_c): class c of a 4-class launch writes pixel (2 a + (c >> 1), 2 b + (c & 1))
+struct DeepClass {
+    int y_oy, y_ox;
+    int row_base;                   // first partial row / workspace tile of this class: c * (pixel tiles)
+};
+__device__ __forceinline__ DeepClass deep_class(const SisrConvDesc& d, int cls) {
+    DeepClass c;
+    const bool multi = d.deep.classes > 1;
+    c.y_oy = multi ? (cls >> 1) : d.y_oy;
+    c.y_ox = multi ? (cls & 1) : d.y_ox;
+    c.row_base = cls * d.deep.tiles_x * d.deep.tiles_q;
+    return c;
+}
+
 // LDS of the epilogue: [row_off 128 ints][red 12 * BN floats][img_r][img_x (each 128 x (BN + 8) bf16, only with res / bnb)]
 // [img_y BN x 132 bf16]
 __host__ __device__ static inline int deep_epi_lds(int BN, bool images) {
@@ -156,7 +170,7 @@ __host__ __device__ static inline int deep_epi_lds(int BN, bool images) {
 // columns 32 NSUB wn ..; acc[ms][ns][i]: row 64 wm + 32 ms + mfma_row(i, lane), column 32 NSUB wn + 32 ns + (lane & 31).
 // Every LDS buffer of the caller is free (a barrier has been passed).
 template <int NSUB>
-__device__ __forceinline__ void deep_epilogue(const SisrConvDesc& d, f32x16 (&acc)[2][NSUB], unsigned char* lds, int mt, int nt) {
+__device__ __forceinline__ void deep_epilogue(const SisrConvDesc& d, f32x16 (&acc)[2][NSUB], unsigned char* lds, int mt, int nt, int cls) {
     const SisrDeepPlan& p = d.deep;
     constexpr int BN = NSUB * 64, WN = NSUB * 32;
     constexpr int RS = BN + 8, YS = DP_BM + 4;
@@ -165,6 +179,7 @@ __device__ __forceinline__ void deep_epilogue(const SisrConvDesc& d, f32x16 (&ac
     const int l31 = lane & 31, kk = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const DeepTile t = deep_tile(d, mt);
+    const DeepClass dc = deep_class(d, cls);
     const bool has_r = d.res != nullptr, has_x = d.bnb_part != nullptr;
     int* row_off = reinterpret_cast<int*>(lds);
     float* red = reinterpret_cast<float*>(lds + 512);
@@ -179,7 +194,7 @@ __device__ __forceinline__ void deep_epilogue(const SisrConvDesc& d, f32x16 (&ac
         int off = -1;
         if (r < p.TH && q < t.NQ && ox < d.Wo) {
             const int n = fdiv(q, p.m_ho), oy = q - n * d.Ho;
-            const int py = oy * d.y_sy + d.y_oy, px = ox * d.y_sx + d.y_ox;
+            const int py = oy * d.y_sy + dc.y_oy, px = ox * d.y_sx + dc.y_ox;
             off = ((n * d.y_H + py) * d.y_W + px) * d.Cout;
         }
         row_off[tid] = off;
@@ -244,10 +259,10 @@ __device__ __forceinline__ void deep_epilogue(const SisrConvDesc& d, f32x16 (&ac
             float nn = red[tid * 3], mu = red[tid * 3 + 1], m2 = red[tid * 3 + 2];
             const float* r = red + (BN + tid) * 3;
             dp_stat_merge(nn, mu, m2, r[0], r[1], r[2]);
-            float* sp = d.stat_part + (int64_t)mt * 2 * d.Cout + cout_base + tid;
+            float* sp = d.stat_part + (int64_t)(dc.row_base + mt) * 2 * d.Cout + cout_base + tid;
             sp[0] = mu;
             sp[d.Cout] = m2;
-            if (tid == 0 && nt == 0) d.cnt_part[mt] = nn;
+            if (tid == 0 && nt == 0) d.cnt_part[dc.row_base + mt] = nn;
         }
     }
 
@@ -330,7 +345,7 @@ __device__ __forceinline__ void deep_epilogue(const SisrConvDesc& d, f32x16 (&ac
         ssl = wave_sum(ssl);
         if (lane == 0) red[4 * BN + wave] = ssl;
         __syncthreads();
-        float* wk = d.bnb_part + (int64_t)(mt * p.n_ntiles + nt) * (2 * d.Cout + 1);
+        float* wk = d.bnb_part + (int64_t)((dc.row_base + mt) * p.n_ntiles + nt) * (2 * d.Cout + 1);
         for (int c = tid; c < d.Cout; c += DP_THREADS) {
             const int cl = c - cout_base;
             float s1 = 0.f, s2 = 0.f;
@@ -380,8 +395,8 @@ __device__ __forceinline__ void deep_epilogue(const SisrConvDesc& d, f32x16 (&ac
 
 // partial tiles of the K split: [tile = mt * n_ntiles + nt][slice][wave][ms][ns][g 4][lane 64][4] fp32
 template <int NSUB>
-__device__ __forceinline__ int64_t deep_ws_index(const SisrDeepPlan& p, int mt, int nt, int slice) {
-    return ((int64_t)(mt * p.n_ntiles + nt) * p.split + slice) * (DP_BM * NSUB * 64);
+__device__ __forceinline__ int64_t deep_ws_index(const SisrDeepPlan& p, int cls, int mt, int nt, int slice) {
+    return ((int64_t)((cls * p.tiles_x * p.tiles_q + mt) * p.n_ntiles + nt) * p.split + slice) * (DP_BM * NSUB * 64);
 }
 
 // ---- the main kernel -------------------------------------------------------------------------------------------------------
@@ -400,8 +415,9 @@ __global__ void __launch_bounds__(DP_THREADS, NSUB == 2 ? 1 : 2) conv_deep_kerne
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kk = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int nt = blockIdx.x, mt = blockIdx.y, slice = blockIdx.z;
-    const int S = d.stride, KH = d.KH;
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int cls = p.classes > 1 ? (int)blockIdx.z / p.split : 0, slice = (int)blockIdx.z - cls * p.split;
+    const int S = d.stride, KH = p.classes > 1 ? d.deep_ckh[cls] : d.KH;
     const DeepTile t = deep_tile(d, mt);
     const int IW = p.IW;
     auto rbase = [&](int q) { const int n = fdiv(q, p.m_ho); return n * p.PR + (q - n * d.Ho) * S; };
@@ -434,7 +450,7 @@ __global__ void __launch_bounds__(DP_THREADS, NSUB == 2 ? 1 : 2) conv_deep_kerne
     const unsigned loff0 = (unsigned)((tid >> 2) * DP_PSB + (tid & 3) * 16);
     const unsigned xbytes = (unsigned)d.N * (unsigned)d.H * (unsigned)d.W * (unsigned)d.Cin * 2u;
     const __amdgpu_buffer_rsrc_t r1 = bf_rsrc(d.x1, xbytes), r2 = bf_rsrc(TWO ? d.x2 : d.x1, xbytes);
-    const __amdgpu_buffer_rsrc_t rw = bf_rsrc(d.wdeep, (unsigned)p.wimg_elems * 2u);
+    const __amdgpu_buffer_rsrc_t rw = bf_rsrc(p.classes > 1 ? d.wdeep_c[cls] : d.wdeep, (unsigned)(p.n_chunk * KH * d.Cout * (KW * 32 + 8)) * 2u);
     const float slope = d.pro_slope_p ? d.pro_slope_p[0] : d.pro_slope;
     const int pro = d.pro_mode;
 
@@ -558,7 +574,7 @@ __global__ void __launch_bounds__(DP_THREADS, NSUB == 2 ? 1 : 2) conv_deep_kerne
 #undef DP_WAIT_BARRIER
 
     if (p.split > 1) {
-        float* ws = d.deep_ws + deep_ws_index<NSUB>(p, mt, nt, slice);
+        float* ws = d.deep_ws + deep_ws_index<NSUB>(p, cls, mt, nt, slice);
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
@@ -572,7 +588,7 @@ __global__ void __launch_bounds__(DP_THREADS, NSUB == 2 ? 1 : 2) conv_deep_kerne
                 }
         return;
     }
-    deep_epilogue<NSUB>(d, acc, lds, mt, nt);
+    deep_epilogue<NSUB>(d, acc, lds, mt, nt, cls);
 }
 
 // sums the K slices of one tile in slice order and runs the epilogue
@@ -582,7 +598,7 @@ __global__ void __launch_bounds__(DP_THREADS, NSUB == 2 ? 1 : 2) conv_deep_finis
     const SisrDeepPlan& p = d.deep;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int nt = blockIdx.x, mt = blockIdx.y, cls = blockIdx.z;
     f32x16 acc[2][NSUB];
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms)
@@ -590,7 +606,7 @@ __global__ void __launch_bounds__(DP_THREADS, NSUB == 2 ? 1 : 2) conv_deep_finis
         for (int ns = 0; ns < NSUB; ++ns)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ms][ns][i] = 0.f;
-    const float* ws = d.deep_ws + deep_ws_index<NSUB>(p, mt, nt, 0);
+    const float* ws = d.deep_ws + deep_ws_index<NSUB>(p, cls, mt, nt, 0);
     constexpr int SLICE = DP_BM * NSUB * 64;
     // slices in groups of four: every load of a group is in flight before the first add (the sum keeps slice order)
     for (int z0 = 0; z0 < p.split; z0 += 4) {
@@ -616,13 +632,13 @@ __global__ void __launch_bounds__(DP_THREADS, NSUB == 2 ? 1 : 2) conv_deep_finis
                     }
                 }
     }
-    deep_epilogue<NSUB>(d, acc, lds, mt, nt);
+    deep_epilogue<NSUB>(d, acc, lds, mt, nt, cls);
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------------
 static inline int dp_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-extern "C" int sisr_conv2d_deep_plan(SisrConvDesc* d, int32_t target_wg) {
+extern "C" int sisr_conv2d_deep_plan(SisrConvDesc* d, int32_t target_wg, int32_t prefer_bn, int32_t classes) {
     if (!d) return SISR_E_BADARG;
     SisrDeepPlan& p = d->deep;
     std::memset(&p, 0, sizeof(p));
@@ -637,9 +653,11 @@ extern "C" int sisr_conv2d_deep_plan(SisrConvDesc* d, int32_t target_wg) {
     // 32-bit byte offsets with 2^31 as the out-of-range marker: bf16 tensors below 2 GB
     if (ypix * d->Cout * 2 >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->Cin * 2 >= (1ll << 31)) return SISR_E_TOOBIG;
     if ((int64_t)d->N * d->Ho >= 65536) return SISR_E_TOOBIG;
-    p.BN = (d->Cout % 128 == 0) ? 128 : 64;
-    if (const char* e = getenv("SISR_DEEP_BN")) if (atoi(e) == 64) p.BN = 64;                  // A/B knob
-    p.n_ntiles = d->Cout / p.BN;
+    if (classes != 1 && classes != 4) return SISR_E_BADARG;
+    if (classes == 4 && (d->KH != 2 || d->KW != 2 || d->stride != 1 || d->pad_y || d->pad_x || d->y_sy != 2 || d->y_sx != 2 ||
+                         d->y_H != 2 * d->Ho || d->y_W != 2 * d->Wo || d->H != d->Ho || d->W != d->Wo))
+        return SISR_E_UNSUPPORTED;
+    p.classes = classes;
     p.n_chunk = d->Cin / 32;
     const int NQ = d->N * d->Ho;
     if (d->Ho % 8 == 0 && d->Wo % 16 == 0) {
@@ -649,6 +667,13 @@ extern "C" int sisr_conv2d_deep_plan(SisrConvDesc* d, int32_t target_wg) {
     } else {
         return SISR_E_UNSUPPORTED;
     }
+    // cout tile: with plenty of pixel tiles 64-cout workgroups (two per CU, each other's stalls covered) measure 20-30 % faster in the
+    // forward role; few pixel tiles, or a caller that announces a heavy prologue, take 128 (half the staging work per MFMA)
+    const int n_mtiles0 = p.tiles_x * p.tiles_q * classes;
+    p.BN = (d->Cout % 128 == 0) ? 128 : 64;
+    if (p.BN == 128 && prefer_bn != 128 && (prefer_bn == 64 || n_mtiles0 >= 128)) p.BN = 64;
+    if (const char* e = getenv("SISR_DEEP_BN")) { const int v = atoi(e); if (v == 64 || (v == 128 && d->Cout % 128 == 0)) p.BN = v; }   // A/B knob
+    p.n_ntiles = d->Cout / p.BN;
     const int pad_bot = std::max(0, (d->Ho - 1) * S + d->KH - 1 - d->pad_y - (d->H - 1));
     p.PR = d->pad_y + d->H + pad_bot;
     if (p.PR < d->Ho * S) return SISR_E_UNSUPPORTED;
@@ -666,7 +691,7 @@ extern "C" int sisr_conv2d_deep_plan(SisrConvDesc* d, int32_t target_wg) {
     if ((int64_t)d->N * p.PR >= 65536 || p.IH_max * p.IW >= 65536) return SISR_E_TOOBIG;
     // K split: reach ~target workgroups, at least two chunks per slice (a slice pays a prologue, an epilogue-sized partial
     // store and its share of the finishing pass)
-    const int base = p.tiles_x * p.tiles_q * p.n_ntiles;
+    const int base = p.tiles_x * p.tiles_q * p.n_ntiles * classes;
     int target = target_wg > 0 ? target_wg : 256;
     if (const char* e = getenv("SISR_DEEP_TARGET")) target = std::max(1, atoi(e));
     int min_cps = 2;
@@ -700,13 +725,13 @@ static int launch_deep_t(const SisrConvDesc* d, hipStream_t st) {
     if (lds_main > 160 * 1024) return SISR_E_TOOBIG;
     static SisrLdsCap cap;
     if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&conv_deep_kernel<NSUB, KW, NITM, TWO>), lds_main, 0)) return e;
-    const dim3 grid(p.n_ntiles, p.tiles_x * p.tiles_q, p.split);
+    const dim3 grid(p.n_ntiles, p.tiles_x * p.tiles_q, p.split * p.classes);
     hipLaunchKernelGGL((conv_deep_kernel<NSUB, KW, NITM, TWO>), grid, dim3(DP_THREADS), lds_main, st, *d);
     SISR_CHECK_LAUNCH();
     if (p.split > 1) {
         static SisrLdsCap capf;
         if (int e = sisr_raise_lds_cap(capf, reinterpret_cast<const void*>(&conv_deep_finish_kernel<NSUB>), epi, 0)) return e;
-        hipLaunchKernelGGL((conv_deep_finish_kernel<NSUB>), dim3(p.n_ntiles, p.tiles_x * p.tiles_q), dim3(DP_THREADS), epi, st, *d);
+        hipLaunchKernelGGL((conv_deep_finish_kernel<NSUB>), dim3(p.n_ntiles, p.tiles_x * p.tiles_q, p.classes), dim3(DP_THREADS), epi, st, *d);
         SISR_CHECK_LAUNCH();
     }
     return 0;
@@ -722,6 +747,7 @@ static int launch_deep_k(const SisrConvDesc* d, hipStream_t st) {
 
 extern "C" int sisr_conv2d_deep_eligible(const SisrConvDesc* d) {
     if (!d || !d->deep.enabled || !d->wdeep) return 0;
+    if (d->deep.classes == 4 && !(d->wdeep_c[0] && d->wdeep_c[1] && d->wdeep_c[2] && d->wdeep_c[3])) return 0;
     if (!d->x_bf16 || !d->y_bf16 || d->x_mode != SISR_X_NHWC || d->y_mode != SISR_Y_NHWC || d->epi_act != SISR_EPI_NONE) return 0;
     if (d->pro_mode == SISR_PRO_RES_AFFINE || d->pro_mode == SISR_PRO_TANH_BWD || d->fin_stat) return 0;
     if ((d->res && !d->res_bf16) || (d->bnb_part && !d->bnbx_bf16)) return 0;
@@ -748,6 +774,6 @@ int sisr_conv2d_deep_launch(const SisrConvDesc* d, hipStream_t st) {
 
 // rows of stat_part / cnt_part (one per pixel tile) or of bnb_part (one per (pixel tile, cout tile)) a launch writes
 int sisr_conv2d_deep_parts(const SisrConvDesc* d) {
-    const int mt = d->deep.tiles_x * d->deep.tiles_q;
+    const int mt = d->deep.tiles_x * d->deep.tiles_q * d->deep.classes;
     return d->bnb_part ? mt * d->deep.n_ntiles : mt;
 }

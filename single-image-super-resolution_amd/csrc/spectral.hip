@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_deep_kernel(const Sis
     for (int cls = 0; cls < 4; ++cls) {
         __bf16* dst = reinterpret_cast<__bf16*>(w.wdp_dcls[cls]);
         if (dst == nullptr) continue;
-        const int KHc = w.c_KH[cls], KWc = w.c_KW[cls], RWc = KWc * 32 + 8;
+        const int KHc = w.c_KH[cls], KWc = w.c_KW[cls], RWc = (w.wdp_cls_kw ? w.wdp_cls_kw : KWc) * 32 + 8;
         for (int i = tid; i < KHc * 32 * RWc; i += SISR_BLOCK) {
             const int row = i / RWc, k = i - row * RWc, rp = row >> 5, ci = row & 31;
             const int r = w.c_R0y[cls] - 2 * rp, sx = w.c_R0x[cls] - 2 * (k >> 5);

@@ -128,6 +128,9 @@ class ConvGeom:
         # trunk-shaped layers (3x3, 64 -> 64, stride 1) whose DATA GRADIENT never arrives with a BatchNorm-backward prologue
         # (the frozen VGG stack): the persistent trunk kernel refuses it, so it is planned for conv_deep.hip instead
         self.deep_dgrad = deep_dgrad
+        # the data gradient of this layer never arrives through a BatchNorm-backward prologue (frozen VGG): its staging is
+        # cheap, so the planner may pick the 64-cout tiles that plenty of pixel tiles favour (sisr_conv2d_deep_plan's prefer_bn)
+        self.light_backward = deep_dgrad
         self._plans = {}
 
     def _deep_ok(self, role, h, w):
@@ -164,9 +167,34 @@ class ConvGeom:
         bf = PRECISION == 'bf16' and self.cout % 32 == 0 and lib.sisr_conv2d_plan_bf16(C.byref(d)) == 0
         if not bf:
             L.check(lib.sisr_conv2d_plan(C.byref(d)), 'sisr_conv2d_plan(dgrad stride-2 class)')
-        elif self._deep_ok(1, h, w) and lib.sisr_conv2d_deep_plan(C.byref(d), 0) == 0:
+        elif self._deep_ok(1, h, w) and lib.sisr_conv2d_deep_plan(C.byref(d), 0, 0 if self.light_backward else 128, 1) == 0:
             bf = 2                                                    # conv_deep.hip
         return (d, r0y, r0x, bf if bf == 2 else bool(bf))
+
+    def _s2_deep_plan(self, lib, n, h, w, ho, wo):
+        """stride-2 data gradient as ONE conv_deep.hip launch over the four output-parity classes (even sizes): -> (descriptor of
+        the 2 x 2-tap class convolution, [(taps y, taps x, R0y, R0x)] per class c = 2 py + px) or None"""
+        if h % 2 or w % 2 or self.k != 3 or self.pad != 1 or not self._deep_ok(1, h, w) or os.environ.get('SISR_DEEP_S2X4', '1') == '0':
+            return None
+        d = L.ConvDesc()
+        d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, ho, wo, self.cout, h // 2, w // 2, self.cin
+        d.KH = d.KW = 2
+        d.stride, d.pad_y, d.pad_x = 1, 0, 0
+        d.y_sy = d.y_sx = 2
+        d.y_oy = d.y_ox = 0
+        d.y_H, d.y_W = h, w
+        if (ho, wo) != (h // 2, w // 2) or lib.sisr_conv2d_plan_bf16(C.byref(d)) != 0:
+            return None
+        if lib.sisr_conv2d_deep_plan(C.byref(d), 0, 0 if self.light_backward else 128, 4) != 0:
+            return None
+        cls = []
+        for py in (0, 1):
+            for px in (0, 1):
+                khc, pady, r0y = _s2_taps(self.k, self.pad, py)
+                kwc, padx, r0x = _s2_taps(self.k, self.pad, px)
+                assert pady == 0 and padx == 0 and khc <= 2 and kwc <= 2
+                cls.append((khc, kwc, r0y, r0x))
+        return d, cls
 
     def plans(self, n, h, w, max_pixel_blocks=None):
         """-> (fwd desc, dgrad desc | [4 class descs] | None, wgrad desc, kinds) where kinds =
@@ -190,7 +218,7 @@ class ConvGeom:
         f_bf = want_bf16 and self.cin % 32 == 0 and lib.sisr_conv2d_plan_bf16(C.byref(f)) == 0
         if not f_bf:
             L.check(lib.sisr_conv2d_plan(C.byref(f)), 'sisr_conv2d_plan(fwd)')
-        elif self._deep_ok(0, h, w) and lib.sisr_conv2d_deep_plan(C.byref(f), 0) == 0:
+        elif self._deep_ok(0, h, w) and lib.sisr_conv2d_deep_plan(C.byref(f), 0, 0, 1) == 0:
             f_bf = 2                                                  # kind 2: conv_deep.hip (its own weight image)
         d = None
         d_bf = False
@@ -205,10 +233,14 @@ class ConvGeom:
             d_bf = want_bf16 and self.cout % 32 == 0 and lib.sisr_conv2d_plan_bf16(C.byref(d)) == 0
             if not d_bf:
                 L.check(lib.sisr_conv2d_plan(C.byref(d)), 'sisr_conv2d_plan(dgrad)')
-            elif self._deep_ok(1, h, w) and lib.sisr_conv2d_deep_plan(C.byref(d), 0) == 0:
+            elif self._deep_ok(1, h, w) and lib.sisr_conv2d_deep_plan(C.byref(d), 0, 0 if self.light_backward else 128, 1) == 0:
                 d_bf = 2
         else:
-            d = [self._s2_class_plan(lib, n, h, w, ho, wo, py, px) for py in (0, 1) for px in (0, 1)]
+            x4 = self._s2_deep_plan(lib, n, h, w, ho, wo) if want_bf16 else None
+            if x4 is not None:
+                d, d_bf = S2x4(*x4), 3                               # kind 3: one launch over the four parity classes
+            else:
+                d = [self._s2_class_plan(lib, n, h, w, ho, wo, py, px) for py in (0, 1) for px in (0, 1)]
         g = L.WgradDesc()
         g.N, g.H, g.W, g.Cin, g.Ho, g.Wo, g.Cout = n, h, w, self.cin, ho, wo, self.cout
         g.KH = g.KW = self.k
@@ -223,8 +255,19 @@ class ConvGeom:
             g.Cout = self.cout
             L.check(lib.sisr_wgrad_plan(C.byref(g), max_pixel_blocks), 'sisr_wgrad_plan')
         g.slab_stride = g.slab_elems + g.CoutPad
-        self._plans[key] = (f, d, g, (f_bf if f_bf == 2 else bool(f_bf), d_bf if d_bf == 2 else bool(d_bf), bool(g_bf)))
+        self._plans[key] = (f, d, g, (f_bf if f_bf == 2 else bool(f_bf), d_bf if d_bf in (2, 3) else bool(d_bf), bool(g_bf)))
         return self._plans[key]
+
+
+class S2x4:
+    """the data gradient of a stride-2 layer planned as one conv_deep.hip launch over its four output-parity classes"""
+
+    def __init__(self, desc, classes):
+        self.desc, self.classes = desc, classes          # classes[c] = (taps y, taps x, R0y, R0x), c = 2 py + px
+
+    def image_slots(self, c, cout_fwd, cin_fwd):
+        """fp32 slots of class c's weight image [cout_fwd / 32][taps y][cin_fwd][2 * 32 + 8] bf16 (KW = 2 row format)"""
+        return ((cout_fwd // 32) * self.classes[c][0] * cin_fwd * 72 + 1) // 2
 
 
 def _s2_taps(k, pad, parity):
@@ -320,7 +363,13 @@ def prepare_weights(items, training, need_dgrad=True, cache=None):
         ldsimg = _trunk_ldsimg(ref.geom, f, d, kinds)
         off_f = alloc(f, kinds[0], lanes[0], ldsimg[0])
         off_d = None
-        if need_dgrad and isinstance(d, list):
+        if need_dgrad and isinstance(d, S2x4):
+            off_d = []
+            for c in range(4):
+                n_ = _align4(d.image_slots(c, ref.geom.cout, ref.geom.cin))
+                off_d.append(('d', dtotal, n_))
+                dtotal += n_
+        elif need_dgrad and isinstance(d, list):
             off_d = [None if cls is None else alloc(cls[0], cls[3]) for cls in d]
         elif need_dgrad and d is not None:
             off_d = alloc(d, kinds[1], lanes[1], ldsimg[1])
@@ -376,7 +425,15 @@ def prepare_weights(items, training, need_dgrad=True, cache=None):
         else:
             t.wpk_fwd = p.wpk_fwd.data_ptr()
             t.f_ldsimg = p.ldsimg[0]
-        if kinds[1] == 2:
+        if kinds[1] == 3:
+            if off_d is not None:
+                has_deep = True
+                t.wdp_cls_kw = 2
+                for ci, ((khc, kwc, r0y, r0x), buf) in enumerate(zip(d.classes, p.wpk_dgrad)):
+                    t.c_KH[ci], t.c_KW[ci], t.c_R0y[ci], t.c_R0x[ci] = khc, kwc, r0y, r0x
+                    if not deep_hit:
+                        t.wdp_dcls[ci] = buf.data_ptr()
+        elif kinds[1] == 2:
             if off_d is not None:
                 has_deep = True
                 if not deep_hit:
@@ -391,7 +448,7 @@ def prepare_weights(items, training, need_dgrad=True, cache=None):
         t.training, t.shuffle2 = int(training), int(gm.shuffle2)
         t.f_CK, t.f_PS, t.f_KROWP, t.f_n_chunk, t.f_CoutPad = (f.plan.CK, f.plan.PS, f.plan.KROWP,
                                                                  f.plan.n_chunk, f.plan.CoutPad)
-        if isinstance(off_d, list):
+        if isinstance(off_d, list) and not isinstance(d, S2x4):
             for ci, (cls, buf) in enumerate(zip(d, p.wpk_dgrad)):
                 if cls is None:
                     continue
@@ -601,6 +658,8 @@ def can_fuse_bn_backward(prep):
     """the data-gradient conv of `prep` can also emit the backward reductions of the BatchNorm its output feeds
     (generic bf16 kernel, one cout tile)"""
     d = prep.plans[1]
+    if isinstance(d, S2x4):
+        return True
     if isinstance(d, list):                       # stride 2: the four parity classes, all on the deep family
         return all(c is not None and c[3] == 2 for c in d)
     if d is None:
@@ -632,6 +691,30 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
     activation when slope is given); returns (out, partial rows for bn_backward_finalize) in that case."""
     lib = L.lib()
     gm = prep.ref.geom
+    if isinstance(prep.plans[1], S2x4):          # stride 2, one launch over the four output-parity classes (conv_deep.hip)
+        x4 = prep.plans[1]
+        d = _copy_struct(x4.desc)
+        assert tuple(dy_op.dims) == (d.N, d.H, d.W, d.Cin) and y_mode == L.Y_NHWC, (dy_op.dims, (d.N, d.H, d.W, d.Cin))
+        dev = dy_op.x1.device
+        f = prep.plans[0]
+        out = torch.empty((f.N, f.H, f.W, gm.cin), dtype=act_dtype(gm.cin), device=dev)
+        dy_op.fill(d)
+        d.bias, d.res, d.y = None, _ptr(res), out.data_ptr()
+        d.y_bf16, d.res_bf16 = _bf(out), _bf(res)
+        for c, buf in enumerate(prep.wpk_dgrad):
+            d.wdeep_c[c], d.deep_ckh[c] = buf.data_ptr(), x4.classes[c][0]
+        ws = _attach_deep(d, prep.wpk_dgrad[3], dev, prep)
+        part = None
+        if bnb is not None:
+            x, consts, slope = bnb
+            assert tuple(x.shape) == tuple(out.shape)
+            d.bnb_x, d.bnbx_bf16, d.bnb_part = x.data_ptr(), _bf(x), d.y
+            rows = lib.sisr_conv2d_bf16_parts(C.byref(d))
+            part = torch.empty((rows, 2 * gm.cin + 1), dtype=torch.float32, device=dev)
+            d.bnb_part = part.data_ptr()
+            _fill_bnb(d, consts, slope)
+        L.check(lib.sisr_conv2d_bf16(C.byref(d), _stream()), 'sisr_conv2d_bf16(dgrad s2 x4)')
+        return out if bnb is None else (out, part)
     if isinstance(prep.plans[1], list):          # stride 2: four output-parity classes
         f = prep.plans[0]
         dev = dy_op.x1.device

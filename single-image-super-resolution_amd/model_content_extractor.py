@@ -40,6 +40,9 @@ def _vgg19_feature_modules(n_layers, width_div=1):
             mods.append(Marker('MaxPool2d(2,2)'))
         else:
             mods.append(Conv2d(cin, v // width_div, 3, 1, 1))
+            # frozen stack: its data gradients never carry a BatchNorm-backward prologue, so the trunk-shaped conv1_2 (64 -> 64)
+            # takes conv_deep.hip for that role and the planner may choose tiles for a light prologue (engine.ConvGeom)
+            mods[-1].geom.deep_dgrad = mods[-1].geom.light_backward = True
             mods.append(Marker('ReLU'))
             cin = v // width_div
     return mods[:n_layers]

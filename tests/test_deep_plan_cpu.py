@@ -25,14 +25,16 @@ def _plan(n, h, w, cin, cout, kh, kw, stride, pad, ho, wo, y=(1, 0, 1, 0, None, 
     d.KH, d.KW, d.stride, d.pad_y, d.pad_x = kh, kw, stride, pad, pad
     d.y_sy, d.y_oy, d.y_sx, d.y_ox = y[:4]
     d.y_H, d.y_W = y[4] or ho, y[5] or wo
-    rc = L.lib().sisr_conv2d_deep_plan(C.byref(d), 0)
+    rc = L.lib().sisr_conv2d_deep_plan(C.byref(d), 0, 0, 1)
     return rc, d
 
 
-def _replay(d, x, wgt):
-    """out[n, oy, ox, co] computed through the kernel's maps: halo image in padded-row space, fragment bases, tap offsets"""
+def _replay(d, x, wgt, KH=None, y_off=None):
+    """out[n, oy, ox, co] computed through the kernel's maps: halo image in padded-row space, fragment bases, tap offsets
+    (KH / y_off: one output-parity class of a 4-class launch -- its tap rows and its output offset)"""
     p = d.deep
-    S, KH, KW = d.stride, d.KH, d.KW
+    S, KH, KW = d.stride, KH or d.KH, d.KW
+    y_oy, y_ox = y_off if y_off is not None else (d.y_oy, d.y_ox)
     N, H, W, Ho, Wo = d.N, d.H, d.W, d.Ho, d.Wo
     NQ = N * Ho
     out = np.zeros((N, d.y_H, d.y_W, d.Cout), np.float64)
@@ -72,7 +74,7 @@ def _replay(d, x, wgt):
                 for kx in range(KW):
                     acc += halo[base + ky * IW + kx] @ wgt[:, :, ky, kx].T
             n, oy = divmod(q, Ho)
-            py, px = oy * d.y_sy + d.y_oy, ox * d.y_sx + d.y_ox
+            py, px = oy * d.y_sy + y_oy, ox * d.y_sx + y_ox
             out[n, py, px] = acc
             written[n, py, px] += 1
     return out, written
@@ -123,7 +125,7 @@ def test_stride2_data_gradient_classes_reproduce_conv_transpose(hw):
             d.KH, d.KW, d.stride, d.pad_y, d.pad_x = khc, kwc, 1, pady, padx
             d.y_sy = d.y_sx = 2
             d.y_oy, d.y_ox, d.y_H, d.y_W = py, px, h, w
-            assert L.lib().sisr_conv2d_deep_plan(C.byref(d), 0) == 0
+            assert L.lib().sisr_conv2d_deep_plan(C.byref(d), 0, 0, 1) == 0
             # class weights as weights_pack_kernel builds them: tap (r', s') = forward tap (R0y - 2 r', R0x - 2 s'), channels swapped
             wc_ = np.zeros((cin, cout, khc, kwc))
             for rp in range(khc):
@@ -132,6 +134,41 @@ def test_stride2_data_gradient_classes_reproduce_conv_transpose(hw):
             o, wr = _replay(d, dy, wc_)
             dx += o
             cover += wr
+    ref = F.conv_transpose2d(torch.from_numpy(dy).permute(0, 3, 1, 2), torch.from_numpy(wgt), stride=2, padding=1,
+                             output_padding=1).permute(0, 2, 3, 1).numpy()
+    assert (cover == 1).all()
+    np.testing.assert_allclose(dx, ref, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize('hw', [(12, 12), (24, 24), (96, 96), (6, 6), (48, 32)])
+def test_stride2_data_gradient_as_one_four_class_launch(hw):
+    """engine.ConvGeom._s2_deep_plan: ONE descriptor (2 x 2 taps, KW = 2 row format) serves the four classes; class c runs its own
+    number of tap rows, reads a weight image whose missing taps are zeros, and scatters to (2 a + py, 2 b + px)"""
+    E = importlib.import_module('single-image-super-resolution_amd.engine')
+    E.set_precision('bf16')
+    try:
+        h, w = hw
+        n, cin, cout = 2, 64, 32
+        gm = E.ConvGeom(cin, cout, 3, 2, 1)
+        x4 = gm._s2_deep_plan(L.lib(), n, h, w, h // 2, w // 2)
+    finally:
+        E.set_precision('fp32')
+    assert x4 is not None
+    d, classes = x4
+    assert d.deep.classes == 4 and d.KW == 2
+    rng = np.random.default_rng(2)
+    dy = rng.standard_normal((n, h // 2, w // 2, cout))
+    wgt = rng.standard_normal((cout, cin, 3, 3))
+    dx = np.zeros((n, h, w, cin))
+    cover = np.zeros((n, h, w), np.int32)
+    for c, (khc, kwc, r0y, r0x) in enumerate(classes):
+        wc_ = np.zeros((cin, cout, khc, 2))                      # KW = 2 row format: a one-tap row carries a zero second tap
+        for rp in range(khc):
+            for sp in range(kwc):
+                wc_[:, :, rp, sp] = wgt[:, :, r0y - 2 * rp, r0x - 2 * sp].T
+        o, wr = _replay(d, dy, wc_, KH=khc, y_off=(c >> 1, c & 1))
+        dx += o
+        cover += wr
     ref = F.conv_transpose2d(torch.from_numpy(dy).permute(0, 3, 1, 2), torch.from_numpy(wgt), stride=2, padding=1,
                              output_padding=1).permute(0, 2, 3, 1).numpy()
     assert (cover == 1).all()
