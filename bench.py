@@ -20,13 +20,16 @@ ONE invocation measures BOTH arithmetic builds, each over exactly --steps timed 
 Each record carries the roofline of the kernel with the LARGEST total time per step (trunk forward conv, trunk
 data-gradient conv and trunk weight gradient are probed live with HIP events on the launch stream) and a
 whole-step fraction (SURVEY 8d algorithmic flops / bytes over the measured step time).  ``cpu_baseline``: the
-oracle (CPU restatement, torch-CPU fp32) timed on this host's cores on the same batch (3 steps, ~10 s each); rank 0,
-N=1 only.
+oracle (CPU restatement, torch-CPU fp32) timed on this host's cores on the same batch (1 warm-up + best of 2 timed steps,
+~6 s each on a 16-core share); rank 0, N=1 only.
 
-``configs`` (N = 1 only; ``--configs none`` skips it): BASELINE.json's configs 2-5 as ONE-GPU iteration rates -- a full SRGAN
-iteration (train.py:45-108: G forward, D step on real + detached fake, G step through D and the VGG content
-extractor, both fused Adam steps) of each config's networks at its sizes in the bf16 build, replayed from two HIP
-graphs, with the algorithmic flops / bytes of one iteration and the fractions of the MI355X peaks they amount to.
+``configs`` (``--configs none`` skips it): BASELINE.json's configs 2-5 as iteration rates over all N ranks -- a full SRGAN
+iteration (train.py:45-108: ONE G forward, D step on real + detached fake, G step through D and the VGG content
+extractor, both fused Adam steps; with N > 1 the gradient buckets of BOTH networks all-reduced from inside their backward
+schedules) of each config's networks at its sizes in the bf16 build, replayed from one segmented HIP graph, with the
+algorithmic flops / bytes of one iteration and the fractions of the MI355X peaks they amount to.  N = 1 times cfg2-cfg5; N > 1
+times the configs BASELINE.json calls "8xMI355X DP" (cfg3, cfg4, cfg5).  BASELINE.json's metric string reads "96^2 crops, x4":
+that workload is ``configs.cfg3``; the top-level value is the north star's headline (x2 generator, LR 96 -> SR 192).
 
 ``--gpus N`` with N > 1 starts the N rank processes itself (``torch.distributed.run``, one per GPU, rendezvous
 on 127.0.0.1) BEFORE anything touches the GPU, unless it already runs under such a launcher (WORLD_SIZE set).
@@ -182,7 +185,7 @@ def _recorded_traffic(kernel_key):
     corrections applied): bench.py cannot run rocprofv3 on itself, so the figure is the one RECORDED under profiles/
     for this kernel by tools/pmc_collect.sh (newest round first), with the commit it was collected at; null when
     absent."""
-    for name in ('r03_traffic.json', 'r02_traffic.json'):
+    for name in ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as fh:
                 rec = json.load(fh)[kernel_key]
@@ -455,8 +458,15 @@ def _fresh_allocator():
     torch.cuda.empty_cache()
 
 
-def bench_config(name, device, iters, log):
-    """-> record of one config: ms per iteration, HR patches/s, its algorithmic work and roofline fractions"""
+def make_config_iteration(name, device, rank, world, use_graph, log):
+    """One full SRGAN iteration of a BASELINE.json config (train.py:45-108, empty replay list) as a callable:
+        fake = G(lr)                      ONCE (train.py:53), its autograd graph kept for the G step
+        D step: D(real), D(fake.detach()), BCE, backward, [gradient all-reduce], Adam           (train.py:58-75)
+        G step: D(fake) * 5e-2 + feature-MSE through the VGG extractor, backward, [all-reduce], Adam   (train.py:82-108)
+    Under HIP-graph replay the whole iteration is ONE GraphedStep cut into segments: at 'd_step' (the discriminator's optimizer
+    step runs between two replayed segments, so the G step sees the stepped D exactly as train.py does) and, with N > 1 ranks, at
+    every gradient bucket either network announces from inside its backward schedule (its all-reduce is issued on the side
+    stream between the segments).  -> (iteration(), info dict)"""
     import torch
     desc, hr_sz, lr_sz, kind, mask = CONFIGS[name]
     E, G = sub('engine'), sub('graph')
@@ -464,7 +474,7 @@ def bench_config(name, device, iters, log):
                            sub('optim'))
     E.set_precision('bf16')
     _fresh_allocator()
-    torch.manual_seed(0)
+    torch.manual_seed(0)                                         # identical replicas on every rank
     if kind == 'progressive_x8':
         mp = sub('model_generator_progressive')
         g1 = mp.GeneratorSuffix(mp.GeneratorProgresiveBase(16, 64), 64)
@@ -479,54 +489,108 @@ def bench_config(name, device, iters, log):
     ext = mce.MaskedVGG(mask, pretrained=False).to(device)       # synthetic weights: the pretrained ones need a remote fetch
     og, od = op.Adam(net_g.parameters(), lr=1e-5), op.Adam(net_d.parameters(), lr=1e-5)
     crit = torch.nn.BCELoss()
-    hr = torch.rand(B, 3, hr_sz, hr_sz, device=device) * 2 - 1
+    gen = torch.Generator().manual_seed(rank)                    # a different shard of patches per rank
+    hr = (torch.rand(B, 3, hr_sz, hr_sz, generator=gen) * 2 - 1).to(device)
     ones, red, zeros = torch.ones(B, device=device), torch.full((B,), .9, device=device), torch.zeros(B, device=device)
+    red_g = red_d = None
+    if world > 1:
+        dist_m = sub('distributed')
+        red_g, red_d = dist_m.GradReducer(net_g, world, name='G:'), dist_m.GradReducer(net_d, world, name='D:')
 
-    def d_part():                       # train.py:45-74
+    def both():
         lr = ut.lr_from_hr(hr, (lr_sz, lr_sz), device=device)
-        fake = net_g(lr)
+        fake = net_g(lr)                                         # train.py:53 -- once
         net_d.zero_grad()
         err_d = crit(net_d(hr).view(-1), red) + crit(net_d(fake.detach()).view(-1), zeros)
         err_d.backward()
-        return err_d
-
-    def g_part():                       # train.py:82-107 (D already stepped)
-        lr = ut.lr_from_hr(hr, (lr_sz, lr_sz), device=device)
-        fake = net_g(lr)
+        if not G.segment_boundary('d_step'):                     # replay: the host runs d_step() between the two segments
+            d_step()                                             # eager: right here
+        if red_d is not None:
+            red_d.enabled = False                                # the G step's pass through D: those gradients are discarded
         net_g.zero_grad()
         err_g = crit(net_d(fake).view(-1), ones) * 5e-2 + torch.mean(torch.pow(ext(hr) - ext(fake), 2))
         err_g.backward()
-        return err_g
-    graphed = True
-    try:
-        d_run, g_run = G.GraphedStep(d_part), G.GraphedStep(g_part)
-    except G.GraphCaptureError as e:
-        log('%s: %s -- launching eagerly instead' % (name, e))
-        d_run, g_run, graphed = d_part, g_part, False
+        if red_d is not None:
+            red_d.enabled = True
+        return err_d, err_g
+
+    def d_step():
+        if red_d is not None:
+            red_d.finish()               # whatever the backward schedule did not announce; the compute stream waits for the exchange
+        od.step()
+
+    def between(tag):
+        if tag == 'd_step':
+            d_step()
+        elif red_d is not None and red_d.owns(tag):
+            red_d.launch_bucket(tag)
+        elif red_g is not None and red_g.owns(tag):
+            red_g.launch_bucket(tag)
+
+    graphed = None
+    if use_graph:
+        try:
+            for r in (red_g, red_d):
+                if r is not None:
+                    r.capture_mode(True)
+            graphed = G.GraphedStep(both, between=between)
+        except G.GraphCaptureError as e:
+            log('%s: %s -- launching eagerly instead' % (name, e))
+            graphed = None
+        finally:
+            for r in (red_g, red_d):
+                if r is not None:
+                    r.capture_mode(False)
 
     def iteration():
-        d_run()
-        od.step()
-        g_run()
+        out = graphed() if graphed is not None else both()
+        if red_g is not None:
+            if graphed is not None:
+                red_g.launch_remaining()
+            red_g.finish()
         og.step()
+        return out
+    info = {'config': desc, 'hr': hr_sz, 'lr': lr_sz, 'generator': kind, 'vgg_mask': mask, 'per_gpu_batch': B, 'dtype': 'bf16',
+            'hip_graph': graphed is not None, 'g_forward_runs': 1,
+            'graph_segments': len(graphed.graphs) if graphed is not None else 0}
+    keep = (net_g, net_d, ext, og, od, graphed, red_g, red_d)
+    return iteration, info, keep
+
+
+def bench_config(name, device, iters, log, rank=0, world=1, use_graph=True):
+    """-> record of one config: ms per iteration, HR patches/s (all ranks), its algorithmic work and roofline fractions"""
+    import torch
+    import torch.distributed as dist
+    desc, hr_sz, lr_sz, kind, mask = CONFIGS[name]
+    iteration, info, keep = make_config_iteration(name, device, rank, world, use_graph, log)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
     for _ in range(3):
         iteration()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(iters):
         iteration()
-    torch.cuda.synchronize()
-    sec = (time.perf_counter() - t0) / iters
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    sec = dt / iters
     flops, nbytes = config_work(kind, hr_sz, lr_sz, mask)
-    rec = {'config': desc, 'hr': hr_sz, 'lr': lr_sz, 'generator': kind, 'vgg_mask': mask, 'per_gpu_batch': B, 'dtype': 'bf16',
-           'iters': iters, 'ms_per_iteration': round(sec * 1e3, 3), 'value': round(B / sec, 1), 'unit': 'HR patches/s',
-           'hip_graph': graphed, 'g_forward_runs': 2,          # (each half owns the autograd state it differentiates; the reference runs G once: the second run is overhead here, not credited work)
-           'alg_flops': flops, 'alg_bytes': nbytes,
-           'roofline': {'bound': 'hbm', 'achieved': round(nbytes / sec / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                        'frac': round(nbytes / sec / 1e9 / PEAK_HBM_GBS, 4), 'traffic': None,
-                        'mfma_tflops': round(flops / sec / 1e12, 1),
-                        'frac_mfma_bf16': round(flops / sec / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}}
-    del net_g, net_d, ext, og, od, d_run, g_run
+    traffic, src = _recorded_traffic('%s_iteration' % name)
+    rec = dict(info)
+    rec.update({'iters': iters, 'ms_per_iteration': round(sec * 1e3, 3), 'value': round(world * B / sec, 1), 'unit': 'HR patches/s',
+                'n_gpus': world, 'alg_flops': flops, 'alg_bytes': nbytes,
+                'roofline': {'bound': 'hbm', 'achieved': round(nbytes / sec / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                             'frac': round(nbytes / sec / 1e9 / PEAK_HBM_GBS, 4), 'traffic': traffic, 'traffic_source': src,
+                             'mfma_tflops': round(flops / sec / 1e12, 1),
+                             'frac_mfma_bf16': round(flops / sec / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}})
+    del iteration, keep
     torch.cuda.empty_cache()
     return rec
 
@@ -542,8 +606,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying HIP graphs')
     ap.add_argument('--precision', choices=['both', 'fp32', 'bf16x3', 'bf16'], default=os.environ.get('SISR_BENCH_PRECISION', 'both'),
                     help='both (default): fp32 parity build at top level + bf16 build as perf_build; or one build only')
-    ap.add_argument('--configs', default='all', help="BASELINE.json configs timed as one-GPU iteration rates (N = 1 only): "
-                    "'all', 'none' or a comma list of cfg2,cfg3,cfg4,cfg5")
+    ap.add_argument('--configs', default='all', help="BASELINE.json configs timed as full SRGAN iteration rates over all ranks: "
+                    "'all' (N = 1: cfg2-cfg5; N > 1: cfg3-cfg5), 'none' or a comma list of cfg2,cfg3,cfg4,cfg5")
     ap.add_argument('--config-iters', type=int, default=10)
     ap.add_argument('--dry-run-ranks', action='store_true',
                     help='launcher self-test: start the ranks, all-reduce a 1 over them and print the count (no GPU work)')
@@ -608,7 +672,8 @@ def main():
     if rank == 0:
         head = records[builds[0]]
         workload = ('SRGAN x2 generator (16 blocks, 64 features, spectral norm) fwd+bwd+Adam with bicubic LR degradation '
-                    'and pixel-MSE x10, per-GPU batch 16 HR 192x192 patches (LR 96x96 -> SR 192x192). ')
+                    'and pixel-MSE x10, per-GPU batch 16 HR 192x192 patches (LR 96x96 -> SR 192x192): the north star\'s headline. '
+                    'BASELINE.json\'s metric string "96^2 crops, x4" is configs.cfg3 of this line. ')
         if len(builds) == 3:
             workload += ('Top level = fp32 parity build (exact-fp32 MFMA, the reference\'s precision, the build that meets every '
                          '1e-3 golden vector); split_build = the same fp32 tensors with the trunk contractions on the bf16 matrix '
@@ -631,17 +696,29 @@ def main():
         if len(builds) == 3:
             rec['split_build'] = records['bf16x3']
             rec['perf_build'] = records['bf16']
-        if world == 1 and args.configs != 'none':
-            names = list(CONFIGS) if args.configs == 'all' else [c for c in args.configs.split(',') if c in CONFIGS]
-            rec['configs'] = {}
-            for name in names:
-                try:
-                    rec['configs'][name] = bench_config(name, device, args.config_iters, log)
-                except Exception as e:                              # noqa: BLE001  (the headline line must still be printed)
-                    rec['configs'][name] = {'error': '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')}
-            sub('engine').set_precision('fp32')
+    if args.configs != 'none':
+        # every rank takes part (the iterations all-reduce both networks' gradients when N > 1); rank 0 keeps the records
+        default = list(CONFIGS) if world == 1 else ['cfg3', 'cfg4', 'cfg5']
+        names = default if args.configs == 'all' else [c for c in args.configs.split(',') if c in CONFIGS]
+        cfg_recs = {}
+        for name in names:
+            try:
+                cfg_recs[name] = bench_config(name, device, args.config_iters, log, rank, world, not args.no_graph)
+            except Exception as e:                              # noqa: BLE001  (the headline line must still be printed)
+                if world > 1:
+                    raise                                       # (a rank that drops out of a collective would hang the others)
+                cfg_recs[name] = {'error': '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')}
+        sub('engine').set_precision('fp32')
+        if rank == 0:
+            rec['configs'] = cfg_recs
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             rec['cpu_baseline'] = cpu_baseline()
+        # the numbers a truncated tail of this (long) line must still show, last
+        rec['summary'] = {'value': rec['value'], 'unit': rec['unit'], 'ms_per_step': rec['ms_per_step'], 'dtype': rec['dtype'], 'n_gpus': world,
+                          'perf_build_value': rec.get('perf_build', {}).get('value'), 'perf_build_ms_per_step': rec.get('perf_build', {}).get('ms_per_step'),
+                          'configs_ms_per_iteration': {k: v.get('ms_per_iteration') for k, v in rec.get('configs', {}).items()},
+                          'roofline_frac': rec['roofline'].get('frac')}
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()

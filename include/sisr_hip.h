@@ -351,6 +351,11 @@ typedef struct SisrWeightGradDesc {
 /* workgroups along grid.y (= dot_work entries) one weight needs; `parts` >= the maximum over the table (host only) */
 int sisr_weights_grad_tiles(const SisrWeightGradDesc *w);
 int sisr_weights_grad(const SisrWeightGradDesc *table_dev, int32_t n, float *dot_work, int32_t parts, void *stream);
+/* the same for a table of 3x3 weights with Cin % 32 == 0, layout 1 and no PixelShuffle permutation: whole 32 x 32 x 9 tiles, one
+ * read of the packed gradient, the spectral-norm rank-one term as an elementwise pass afterwards (the discriminator's 8 convs:
+ * 166 -> ~25 us per backward).  dot_work: n * ceil(max_cout / 32) * (max_cin / 32) floats. */
+int sisr_weights_grad_fast(const SisrWeightGradDesc *table_dev, int32_t n, float *dot_work, int32_t max_cout, int32_t max_cin,
+                           void *stream);
 
 /* ---- BatchNorm2d (training) pieces that are not fused into the convolutions ------------------
  * finalize: merge the per-tile (mean, M2) partials (Chan et al.), produce the fused apply

@@ -136,6 +136,7 @@ _SIGS = {
     'sisr_weights_pack': [_f, _i32, _i32, _i32, _f],
     'sisr_weights_pack_deep': [_f, _i32, _i32, _i32, _f],
     'sisr_weights_grad': [_f, _i32, _f, _i32, _f],
+    'sisr_weights_grad_fast': [_f, _i32, _f, _i32, _i32, _f],
     'sisr_weights_grad_tiles': [C.POINTER(WeightGradDesc)],
     'sisr_bn_finalize': [_f, _f, _i32, _i32, _f, _f, _f, _f, _f32, _f32, _f, _f, _f, _f, _f],
     'sisr_bn_eval_consts': [_f, _f, _f, _f, _f32, _i32, _f, _f, _f],

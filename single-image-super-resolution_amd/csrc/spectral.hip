@@ -521,6 +521,65 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_grad_kernel(const SisrWeig
     wgt_tile<1>(w, blockIdx.y, lds, gw, inv);
 }
 
+// ---- fast path of the weight-gradient epilogue for the 3x3 layers of the bf16 build (slab layout 1, channels in 32s) -------------
+// The generic pair above cuts a 512 x 512 x 3 x 3 weight into 2,304 tiles of 32 rows and reads it twice (dot, then gradient): 166 us
+// per discriminator backward.  Here a workgroup takes a whole 32-cout x 32-cin x 9-tap tile (288 packed rows of 128 bytes in,
+// 32 OIHW rows of 1,152 contiguous bytes out) through LDS ONCE: it writes grad = G / sigma and its share of <G, W_orig>; the
+// rank-one spectral-norm term -<G, W> u v^T / sigma is an elementwise pass over the finished OIHW gradient afterwards.
+__global__ void __launch_bounds__(SISR_BLOCK) weights_grad_fast_kernel(const SisrWeightGradDesc* table, float* dot_part) {
+    __shared__ float tile[288][33];
+    __shared__ float scratch[8];
+    const SisrWeightGradDesc w = table[blockIdx.x];
+    const int cb = blockIdx.y, kb = blockIdx.z, tid = threadIdx.x;
+    const int ncb = (w.Cout + 31) >> 5, nkb = w.Cin >> 5;
+    if (cb >= ncb || kb >= nkb) return;
+    if (cb == 0 && kb == 0 && w.grad_bias != nullptr && w.dbias_pk != nullptr)
+        for (int co = tid; co < w.Cout; co += SISR_BLOCK) w.grad_bias[co] = w.dbias_pk[co];
+    float part = 0.f;
+    if (w.grad != nullptr) {
+        const float inv = w.u_used != nullptr ? 1.f / w.sigma[0] : 1.f;
+        // packed rows (tap, ci) of chunk kb: dwpk[((kb * 9 + tap) * 32 + ci) * CoutPad + cb * 32 + c]
+        const float* src = w.dwpk + (int64_t)kb * 288 * w.CoutPad + cb * 32;
+        for (int i = tid; i < 288 * 32; i += SISR_BLOCK) {
+            const int row = i >> 5, c = i & 31;
+            tile[row][c] = (cb * 32 + c < w.CoutPad) ? src[(int64_t)row * w.CoutPad + c] : 0.f;
+        }
+        __syncthreads();
+        // OIHW rows: grad[co][kb * 32 + ci][tap], 288 contiguous floats per cout; element e = ci * 9 + tap <- tile[tap * 32 + ci][co]
+        for (int i = tid; i < 32 * 288; i += SISR_BLOCK) {
+            const int co = i / 288, e = i - co * 288;
+            if (cb * 32 + co >= w.Cout) continue;
+            const int ci = e / 9, tap = e - ci * 9;
+            const float g = tile[tap * 32 + ci][co];
+            const int64_t o = ((int64_t)(cb * 32 + co) * w.Cin + kb * 32) * 9 + e;
+            if (w.u_used != nullptr) part += g * w.w_orig[o];
+            w.grad[o] = g * inv;
+        }
+    }
+    const float tot = block_sum(part, scratch);
+    if (tid == 0) dot_part[((int64_t)blockIdx.x * gridDim.y + cb) * gridDim.z + kb] = tot;
+}
+
+// grad[co][j] -= (<G, W_orig> / sigma^2) u[co] v[j]      (W = W_orig / sigma; dW_orig = (G - <G, W> u v^T) / sigma)
+__global__ void __launch_bounds__(SISR_BLOCK) weights_grad_rank1_kernel(const SisrWeightGradDesc* table, const float* dot_part,
+                                                                        int tiles_y, int tiles_z) {
+    __shared__ float scratch[8];
+    const SisrWeightGradDesc w = table[blockIdx.x];
+    if (w.u_used == nullptr || w.grad == nullptr) return;
+    const int ncb = (w.Cout + 31) >> 5, nkb = w.Cin >> 5, tid = threadIdx.x;
+    float dot = 0.f;
+    for (int k = tid; k < ncb * nkb; k += SISR_BLOCK) dot += dot_part[((int64_t)blockIdx.x * tiles_y + k / nkb) * tiles_z + k % nkb];
+    dot = block_sum(dot, scratch);                                      // fixed partition and order: every workgroup gets the same bits
+    const float sigma = w.sigma[0];
+    const float coef = dot / (sigma * sigma);
+    const int cols = w.Cin * 9;
+    const int64_t total = (int64_t)w.Cout * cols;
+    for (int64_t e = (int64_t)blockIdx.y * SISR_BLOCK + tid; e < total; e += (int64_t)gridDim.y * SISR_BLOCK) {
+        const int co = (int)(e / cols), j = (int)(e - (int64_t)co * cols);
+        w.grad[e] -= coef * w.u_used[co] * w.v_used[j];
+    }
+}
+
 static int parts_for(int64_t elems) {           // workgroups per weight for the element-wise multi-tensor kernels
     const int64_t want = (elems + 4095) / 4096;   // ~16 elements per thread
     return (int)std::max<int64_t>(16, std::min<int64_t>(want, 1024));
@@ -572,6 +631,21 @@ extern "C" int sisr_weights_prepare(const SisrWeightDesc* table_dev, int32_t n, 
 extern "C" int sisr_weights_grad_tiles(const SisrWeightGradDesc* w) {
     if (!w || w->Cout <= 0 || w->Cin <= 0 || w->KH <= 0 || w->KW <= 0 || (w->layout != 1 && w->CK <= 0)) return SISR_E_BADARG;
     return wgt_tiles(*w);
+}
+
+// every weight of the table: 3x3, Cin % 32 == 0, layout 1 (bf16-kernel slabs), no PixelShuffle permutation.
+// dot_work: n * ceil(max_cout / 32) * (max_cin / 32) floats.
+extern "C" int sisr_weights_grad_fast(const SisrWeightGradDesc* table_dev, int32_t n, float* dot_work, int32_t max_cout,
+                                      int32_t max_cin, void* stream) {
+    if (!table_dev || n <= 0 || !dot_work || max_cout <= 0 || max_cin < 32) return SISR_E_BADARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int ty = (max_cout + 31) / 32, tz = max_cin / 32;
+    hipLaunchKernelGGL(weights_grad_fast_kernel, dim3(n, ty, tz), dim3(SISR_BLOCK), 0, st, table_dev, dot_work);
+    SISR_CHECK_LAUNCH();
+    const int parts = (int)std::max<int64_t>(8, std::min<int64_t>(((int64_t)max_cout * max_cin * 9 + 4095) / 4096, 512));
+    hipLaunchKernelGGL(weights_grad_rank1_kernel, dim3(n, parts), dim3(SISR_BLOCK), 0, st, table_dev, dot_work, ty, tz);
+    SISR_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int sisr_weights_grad(const SisrWeightGradDesc* table_dev, int32_t n, float* dot_work, int32_t parts,

@@ -24,9 +24,14 @@ Under HIP-graph replay (graph.GraphedStep) collectives are not captured: the sch
 at each flush point (graph.segment_boundary) and ``launch_bucket(tag)`` issues that bucket's reduction
 between two replayed segments -- same overlap, the exchange stays ordinary stream work.
 
+The discriminator's schedule (discriminator_engine.run_backward) announces too: the classifier head first -- its 75-302 MB weight
+gradient is 94 % of D's bytes and the FIRST tensor the backward pass produces, so its all-reduce has the whole conv stack's
+backward to hide behind -- then the conv layers deepest first.  D runs one backward pass per forward of the loss (real batch, fake
+batch, train.py:132,156); every pass announces its own gradients and autograd adds the reduced passes (mean of a sum = sum of
+means).  ``enabled = False`` mutes a reducer for a pass whose gradients are discarded (the G step's pass through D, train.py:174).
+
 ``all_reduce_mean()`` is the plain post-backward form (everything that has a ``.grad`` and was not
-already reduced during the backward pass): the path for modules used without ``attach`` (e.g. the
-discriminator, whose several forward calls per loss accumulate into one gradient).
+already reduced during the backward pass): the path for modules used without ``attach``.
 """
 import torch
 import torch.distributed as dist
@@ -38,8 +43,16 @@ FINAL = 'final'        # tag of the last bucket a backward schedule announces (n
 
 
 class GradReducer:
-    def __init__(self, params, world_size=None, bucket_bytes=32 << 20, inplace_bytes=4 << 20, group=None):
+    def __init__(self, params, world_size=None, bucket_bytes=32 << 20, inplace_bytes=4 << 20, group=None, name=''):
         module = params if isinstance(params, torch.nn.Module) else None
+        # `name` prefixes the tags this reducer hands to graph.segment_boundary(): two reducers captured into one GraphedStep (the
+        # discriminator's and the generator's in a joint SRGAN iteration) must not collide on 'final'.  A network that runs several
+        # backward passes per sweep (D on the real and on the fake batch, train.py:132,156) announces every pass: each gets its own
+        # sequence number, and -- the mean being linear -- reducing the passes separately and letting autograd add them is the mean of
+        # the sum (twice the bytes of reducing the sum; the passes are what overlaps with the schedule that produces them).
+        self.name = name
+        self.enabled = True           # False: ready() is a no-op (the G step's pass through D: those gradients are discarded)
+        self._seq = 0
         plist = list(module.parameters()) if module is not None else list(params)
         self.params = [p for p in plist if p.requires_grad]
         self.group = group
@@ -57,6 +70,7 @@ class GradReducer:
         if cur:
             self.buckets.append(cur)
         self._side = None
+        self._flat = {}               # bucket layout -> (flat message buffer, its per-tensor views)
         self._done = set()            # id(param) reduced during the current backward pass
         self._dirty = False           # side stream holds work the compute stream has not waited for
         self._capturing = False
@@ -75,7 +89,7 @@ class GradReducer:
     def capture_mode(self, on):
         self._capturing = bool(on)
         if on:
-            self._captured, self._launched = {}, set()
+            self._captured, self._launched, self._seq = {}, set(), 0
 
     def _streams(self, device):
         if device.type != 'cuda':
@@ -88,36 +102,43 @@ class GradReducer:
     def ready(self, pairs, tag):
         """pairs: [(parameter, its final gradient tensor)] produced since the previous call; tag: schedule position"""
         pairs = [(p, g) for p, g in pairs if g is not None and p.requires_grad]
-        if self.world <= 1 or not pairs:
+        if self.world <= 1 or not pairs or not self.enabled:
             return
         if self._capturing:
-            self._captured[tag] = ([g for _, g in pairs], [id(p) for p, _ in pairs])
-            G.segment_boundary(tag)                     # the capture is cut here; launch_bucket(tag) runs at replay
-            return
+            utag = '%s%s#%d' % (self.name, tag, self._seq)      # unique per announcement (several passes use the same schedule tags)
+            if G.segment_boundary(utag):                # the capture is cut here; launch_bucket(utag) runs at replay
+                self._seq += 1
+                self._captured[utag] = ([g for _, g in pairs], [id(p) for p, _ in pairs], tag == FINAL)
+                return
+            # (not inside a capture: a warm-up run of the function that is about to be captured -- ordinary eager exchange)
         self._launch([g for _, g in pairs])
         self._done.update(id(p) for p, _ in pairs)
         self.stats['early_buckets'] += 1
 
     def backward_end(self):
         """end of the schedule: from here on autograd may read (clone / accumulate) the announced gradients"""
-        if not self._capturing:
+        if not self._capturing and self.enabled:
             self._join()
+
+    def owns(self, tag):
+        """the tag of a replayed segment boundary belongs to this reducer"""
+        return tag in self._captured
 
     # ---- graph replay -----------------------------------------------------------------------------------------
     def launch_bucket(self, tag):
         """between two replayed graph segments: reduce the (static) gradients the finished segment produced"""
-        grads, ids = self._captured.get(tag, (None, ()))
+        grads, ids, last = self._captured.get(tag, (None, (), False))
         if grads and self.world > 1:
             self._launch(grads, static=True)
             self._launched.add(tag)
             self._done.update(ids)
             self.stats['early_buckets'] += 1
-        if tag == FINAL:
+        if last:
             self._join()        # the segment that follows holds autograd's hand-over of ALL gradients to the parameters
 
     def launch_remaining(self):
         """after the last replayed segment: buckets whose boundary closed the capture (no segment followed them)"""
-        for tag, (grads, ids) in self._captured.items():
+        for tag, (grads, ids, _) in self._captured.items():
             if tag not in self._launched and self.world > 1:
                 self._launch(grads, static=True)
                 self._done.update(ids)
@@ -174,7 +195,13 @@ class GradReducer:
             self._allreduce_mean_(g)
         if len(small) == 1 and small[0].is_contiguous():
             self._allreduce_mean_(small[0])
-        elif small:                                      # one message for all of them
-            flat = torch.cat([g.reshape(-1) for g in small])
+        elif small:                                      # one message for all of them, through a PERSISTENT flat buffer
+            key = tuple((g.numel(), g.dtype) for g in small)
+            ent = self._flat.get(key)
+            if ent is None:                              # (one per bucket layout: allocated once, not per step)
+                flat = torch.empty(sum(g.numel() for g in small), dtype=small[0].dtype, device=small[0].device)
+                ent = self._flat[key] = (flat, list(flat.split([g.numel() for g in small])))
+            flat, views = ent
+            torch._foreach_copy_(views, [g.reshape(-1) for g in small])
             self._allreduce_mean_(flat)
-            torch._foreach_copy_(small, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in small]), small)])
+            torch._foreach_copy_([g.reshape(-1) for g in small], views)

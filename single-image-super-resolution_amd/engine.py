@@ -867,11 +867,27 @@ class WeightGradBatch:
         """returns {id(ConvRef): (grad_w or None, grad_b or None)}"""
         if not self.items:
             return {}
-        lib = L.lib()
-        table = (L.WeightGradDesc * len(self.items))()
+        # 3x3 layers whose gradient slabs come from the bf16 kernels (layout 1) with channels in 32s take the whole-tile
+        # un-packing (sisr_weights_grad_fast); the rest (9x9 / 3-channel / fp32-slab layers) the generic pair
+        fast, slow = [], []
+        for it in self.items:
+            gm, g = it[0].ref.geom, it[0].plans[2]
+            ok = (it[0].kinds[2] and gm.k == 3 and gm.cin % 32 == 0 and gm.cout % 32 == 0 and not gm.shuffle2
+                  and g.CoutPad >= gm.cout and os.environ.get('SISR_WGRAD_FAST', '1') != '0')
+            (fast if ok else slow).append(it)
         res = {}
-        dev = self.items[0][1].device
-        for i, (p, red, want_w, want_b) in enumerate(self.items):
+        self._keep = []
+        for group, is_fast in ((fast, True), (slow, False)):
+            if group:
+                res.update(self._run_group(group, is_fast))
+        return res
+
+    def _run_group(self, items, is_fast):
+        lib = L.lib()
+        table = (L.WeightGradDesc * len(items))()
+        res = {}
+        dev = items[0][1].device
+        for i, (p, red, want_w, want_b) in enumerate(items):
             g = p.plans[2]
             gm = p.ref.geom
             t = table[i]
@@ -886,11 +902,15 @@ class WeightGradBatch:
             t.layout = 1 if p.kinds[2] else 0
             res[id(p.ref)] = (gw, gb)
         tab = _table_to_device(table, dev)
-        parts = max(L.check_count(lib.sisr_weights_grad_tiles(C.byref(t)), 'sisr_weights_grad_tiles') for t in table)
-        work = torch.empty((parts * len(self.items),), dtype=torch.float32, device=dev)
-        L.check(lib.sisr_weights_grad(tab.data_ptr(), len(self.items), work.data_ptr(), parts, _stream()),
-                'sisr_weights_grad')
-        self._keep = (tab, work)
+        if is_fast:
+            mco, mci = max(it[0].ref.geom.cout for it in items), max(it[0].ref.geom.cin for it in items)
+            work = torch.empty((len(items) * ((mco + 31) // 32) * (mci // 32),), dtype=torch.float32, device=dev)
+            L.check(lib.sisr_weights_grad_fast(tab.data_ptr(), len(items), work.data_ptr(), mco, mci, _stream()), 'sisr_weights_grad_fast')
+        else:
+            parts = max(L.check_count(lib.sisr_weights_grad_tiles(C.byref(t)), 'sisr_weights_grad_tiles') for t in table)
+            work = torch.empty((parts * len(items),), dtype=torch.float32, device=dev)
+            L.check(lib.sisr_weights_grad(tab.data_ptr(), len(items), work.data_ptr(), parts, _stream()), 'sisr_weights_grad')
+        self._keep.append((tab, work))
         return res
 
 

@@ -82,6 +82,74 @@ def main():
     step(); red2.launch_remaining(); red2.finish(); opt2.step()
     res['graph_params_identical'] = same_on_all_ranks()
     res['graph_stats'] = dict(red2.stats)
+    # ---- the joint SRGAN iteration (train.py:45-108): ONE G forward, D step (two backward passes through D, every pass announcing
+    # its buckets: head first), the discriminator's Adam step between two replayed segments, G step with the D reducer muted ----
+    md, mce = sub('model_discriminator'), sub('model_content_extractor')
+    torch.manual_seed(1)
+    net_g = mg.Generator(4, 64, 256, [2], use_sn=True).to(dev).train()
+    net_d = md.Discriminator((3, 32, 32), [64, 64, 128, 128, 256], [1, 2, 1, 2, 1]).to(dev).train()     # 5 convs: fc | convs3 | final
+    ext = mce.MaskedVGG(0b00010, pretrained=False).to(dev)
+    sg, sd = {k: v.clone() for k, v in net_g.state_dict().items()}, {k: v.clone() for k, v in net_d.state_dict().items()}
+    crit = torch.nn.BCELoss()
+    nb = hr.shape[0]
+    ones, redl, zeros = torch.ones(nb, device=dev), torch.full((nb,), .9, device=dev), torch.zeros(nb, device=dev)
+
+    def all_same(net):
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        lo, hi = flat.clone(), flat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return bool(torch.equal(lo, hi))
+    for mode in ('eager', 'graph'):
+        net_g.load_state_dict(sg); net_d.load_state_dict(sd)
+        og, od = op.Adam(net_g.parameters(), lr=1e-4), op.Adam(net_d.parameters(), lr=1e-4)
+        rg, rd = D.GradReducer(net_g, world, name='G:'), D.GradReducer(net_d, world, name='D:')
+
+        def d_step():
+            rd.finish()
+            od.step()
+
+        def both():
+            lr = ut.lr_from_hr(hr, (16, 16), device=dev)
+            fake = net_g(lr)
+            net_d.zero_grad()
+            err_d = crit(net_d(hr).view(-1), redl) + crit(net_d(fake.detach()).view(-1), zeros)
+            err_d.backward()
+            if not G.segment_boundary('d_step'):
+                d_step()
+            rd.enabled = False
+            net_g.zero_grad()
+            err_g = crit(net_d(fake).view(-1), ones) * 5e-2 + torch.mean(torch.pow(ext(hr) - ext(fake), 2))
+            err_g.backward()
+            rd.enabled = True
+            return err_d, err_g
+
+        def between(tag):
+            if tag == 'd_step':
+                d_step()
+            elif rd.owns(tag):
+                rd.launch_bucket(tag)
+            elif rg.owns(tag):
+                rg.launch_bucket(tag)
+        if mode == 'graph':
+            rg.capture_mode(True); rd.capture_mode(True)
+            step = G.GraphedStep(both, between=between)
+            rg.capture_mode(False); rd.capture_mode(False)
+            net_g.load_state_dict(sg); net_d.load_state_dict(sd)
+            og.state.clear(); od.state.clear()
+            res['joint_graph_segments'] = len(step.graphs)
+            rd.stats, rg.stats = {'early_buckets': 0, 'late_buckets': 0}, {'early_buckets': 0, 'late_buckets': 0}     # (the warm-up runs exchanged eagerly)
+        for _ in range(2):
+            if mode == 'graph':
+                step(); rg.launch_remaining()
+            else:
+                both()
+            rg.finish()
+            og.step()
+        res['joint_%s_g_identical' % mode], res['joint_%s_d_identical' % mode] = all_same(net_g), all_same(net_d)
+        res['joint_%s_d_stats' % mode], res['joint_%s_g_stats' % mode] = dict(rd.stats), dict(rg.stats)
+        lossv = [float(v) for v in (both() if mode == 'eager' else step())]
+        res['joint_%s_losses_finite' % mode] = all(0 < v < 100 for v in lossv)
     torch.cuda.synchronize()
     if rank == 0:
         print('DP_REHEARSAL ' + json.dumps(res), flush=True)

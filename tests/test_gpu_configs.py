@@ -173,3 +173,69 @@ def test_cfg2_joint_srgan_iteration_bf16_eager_vs_graph_replay():
                 assert float((ds[k] - d1[k]).abs().max()) <= 1e-6 * max(1.0, float(d1[k].abs().max())), k
     finally:
         E.set_precision('fp32')
+
+
+def test_cfg2_iteration_with_one_generator_forward_eager_vs_segmented_replay():
+    """train.py:53,60 runs G ONCE per iteration and reuses `fake` (detached for the D step, with its graph for the G step).  The
+    iteration as ONE GraphedStep cut at 'd_step' (the discriminator's Adam step runs between the two replayed segments, the G step
+    differentiates through the autograd graph the first segment built) gives the losses and parameters of the eager iteration."""
+    E, G = pkg('engine'), pkg('graph')
+    mg, md, mce, ut, op = (pkg('model_generator'), pkg('model_discriminator'), pkg('model_content_extractor'),
+                           pkg('utils'), pkg('optim'))
+    E.set_precision('bf16')
+    try:
+        def setup():
+            dev = torch.device('cuda')
+            torch.manual_seed(0)
+            net_g = mg.Generator(16, 64, 256, [2], use_sn=True).to(dev).train()
+            net_d = md.Discriminator((3, 96, 96), FEATS, STRIDES).to(dev).train()
+            ext = mce.MaskedVGG(0b00010, pretrained=False).to(dev)
+            og, od = op.Adam(net_g.parameters(), lr=1e-5), op.Adam(net_d.parameters(), lr=1e-5)
+            crit = torch.nn.BCELoss()
+            hr = _rand((B, 3, 96, 96), 51)
+            ones, red, zeros = torch.ones(B, device=dev), torch.full((B,), .9, device=dev), torch.zeros(B, device=dev)
+
+            def both():
+                lr = ut.lr_from_hr(hr, (48, 48), device=dev)
+                fake = net_g(lr)
+                net_d.zero_grad()
+                err_d = crit(net_d(hr).view(-1), red) + crit(net_d(fake.detach()).view(-1), zeros)
+                err_d.backward()
+                if not G.segment_boundary('d_step'):
+                    od.step()
+                net_g.zero_grad()
+                err_g = crit(net_d(fake).view(-1), ones) * 5e-2 + torch.mean(torch.pow(ext(hr) - ext(fake), 2))
+                err_g.backward()
+                return err_d, err_g
+            return net_g, net_d, og, od, both
+        net_g, net_d, og, od, both = setup()
+        ref_losses = []
+        for _ in range(3):
+            ed, eg = both()
+            og.step()
+            ref_losses.append((float(ed), float(eg)))
+        g1, d1 = _snapshot(net_g), _snapshot(net_d)
+        assert all(0 < a < 100 and 0 < b < 100 for a, b in ref_losses)
+
+        net_g, net_d, og, od, both = setup()
+        state_g, state_d = _snapshot(net_g), _snapshot(net_d)
+        step = G.GraphedStep(both, between=lambda tag: od.step() if tag == 'd_step' else None)
+        assert len(step.graphs) == 2
+        net_g.load_state_dict(state_g); net_d.load_state_dict(state_d)             # the warm-ups advanced SN / BN / Adam state
+        og.state.clear(); od.state.clear()
+        losses = []
+        for _ in range(3):
+            ed, eg = step()
+            og.step()
+            losses.append((float(ed), float(eg)))
+        for (a, b), (c, d) in zip(losses, ref_losses):
+            assert abs(a - c) <= 1e-6 * max(1.0, abs(c)) and abs(b - d) <= 1e-6 * max(1.0, abs(d)), (losses, ref_losses)
+        gs, ds = _snapshot(net_g), _snapshot(net_d)
+        for k in g1:
+            if g1[k].is_floating_point():
+                assert float((gs[k] - g1[k]).abs().max()) <= 1e-6 * max(1.0, float(g1[k].abs().max())), k
+        for k in d1:
+            if d1[k].is_floating_point():
+                assert float((ds[k] - d1[k]).abs().max()) <= 1e-6 * max(1.0, float(d1[k].abs().max())), k
+    finally:
+        E.set_precision('fp32')

@@ -33,7 +33,15 @@ def test_two_ranks_end_a_step_with_identical_parameters():
         raise AssertionError('dp_rehearsal failed (full output: gpurun_out/dp_rehearsal.err):\n' + '\n'.join(tb[-25:]))
     line = [l for l in r.stdout.splitlines() if l.startswith('DP_REHEARSAL ')][-1]
     res = json.loads(line[len('DP_REHEARSAL '):])
+    print(json.dumps(res))
     assert res['eager_grad_err'] < 1e-6 and res['graph_grad_err'] < 1e-6, res
     assert res['eager_params_identical'] and res['graph_params_identical'], res
     assert res['eager_stats'] == {'early_buckets': 3, 'late_buckets': 0}, res     # tail | blocks4 | final, all from inside backward
     assert res['graph_segments'] == 4, res                     # tail | blocks4 | final | autograd hand-over
+    # the joint D + G iteration: both networks end identical on both ranks, eager and replayed; the discriminator's two backward
+    # passes of the D step each announced head / convs / final from inside the schedule, its G-step pass announced nothing
+    for mode in ('eager', 'graph'):
+        assert res['joint_%s_g_identical' % mode] and res['joint_%s_d_identical' % mode], res
+        assert res['joint_%s_losses_finite' % mode], res
+        assert res['joint_%s_d_stats' % mode]['late_buckets'] == 0 and res['joint_%s_d_stats' % mode]['early_buckets'] >= 2 * 2 * 3, res
+    assert res['joint_graph_segments'] >= 8, res
