@@ -168,6 +168,29 @@ int sisr_conv2d_f32(const SisrConvDesc *d, void *stream);
  * Replaces the weight/bias part of convolution_backward for the call sites above.  The input
  * operand (x*, p*, x_mode, pro_*) and the output-gradient operand (g*, q*, g_mode, gpro_*) take
  * the same prologue modes.  Each block writes one fp32 partial slab; sisr_wgrad_reduce sums them. */
+/* Plan of wgrad_deep.hip (bf16 build, filled by sisr_wgrad_deep_plan after sisr_wgrad_plan_bf16): the weight gradient of the 3x3
+ * layers with channels in 64s (the discriminator's conv stack, the generator's trunk at sizes the persistent kernel does not take).
+ * A workgroup owns 64 input channels x 64 output channels x all 9 taps (nine 32 x 32 accumulators per wave: the whole block of the
+ * gradient stays in registers over all of the workgroup's pixel tiles) and a share of the pixel tiles; the tiles are conv_deep.hip's
+ * (rows of the flattened (image, row) space, so 6 x 6 .. 24 x 24 maps waste no MFMA rows), the contraction runs over the tile's
+ * positions in HALO coordinates -- dy is laid out on the pitch of the x halo, so that tap (ky, kx) is the x image shifted by a
+ * constant -- and both operands are staged one tile ahead. */
+typedef struct SisrWgradDeepPlan {
+    int32_t enabled;
+    int32_t TH, TW, tiles_x, tiles_q, n_tiles;
+    int32_t PR;                     /* padded x rows per image                                                   */
+    int32_t IW, IH_max;             /* x halo: pitch (even for stride 2), most rows of any tile                  */
+    int32_t IWd, IHd_max;           /* dy image in halo coordinates: pitch (IW, or IW / 2 for stride 2), rows    */
+    int32_t NPOS_max;               /* positions of the contraction per tile, a multiple of 16                   */
+    int32_t XP_max;                 /* x halo pixels incl. the slack the last K step reads                       */
+    int32_t NITX, NITD;             /* 16-byte staging items per thread (x, dy)                                  */
+    int32_t n_pb, tiles_per_pb;     /* pixel blocks (= slabs) and tiles per block                                */
+    int32_t n_cib, n_cob;           /* 64-channel blocks of Cin / Cout                                           */
+    int32_t lds_bytes;
+    int32_t slab_bf16;              /* the gradient part of a slab row is bf16 (sisr_wgrad_bf16_slab_lead)       */
+    uint32_t m_tiles_x, m_tw, m_ho, m_pr, m_iw, m_iwd;
+} SisrWgradDeepPlan;
+
 typedef struct SisrWgradDesc {
     const float *x1, *x2, *pa, *pb, *pd, *ps, *pt;   /* conv-input operand                    */
     const float *g1, *g2, *qa, *qb, *qd, *qs, *qt;   /* output-gradient operand               */
@@ -191,6 +214,7 @@ typedef struct SisrWgradDesc {
     int32_t x_bf16, g_bf16;                  /* storage type of x1/x2 and of g1/g2 (0: fp32, 1: bf16) */
     int32_t mfma_split;                      /* fp32 operands, trunk geometry: as SisrConvDesc.mfma_split */
     int64_t slab_stride;                     /* set by the caller after planning              */
+    SisrWgradDeepPlan deep;                  /* wgrad_deep.hip (enabled: sisr_conv2d_wgrad_bf16 runs the descriptor there)  */
 } SisrWgradDesc;
 
 int sisr_wgrad_plan(SisrWgradDesc *d, int32_t max_pixel_blocks);
@@ -238,6 +262,12 @@ int sisr_conv2d_toimage_eligible(const SisrConvDesc *d);
 /* ... and with fp32 NHWC tensors (fp32 parity build; exact fp32 MFMA) behind sisr_conv2d_f32 */
 int sisr_conv2d_toimage_f32_eligible(const SisrConvDesc *d);
 int sisr_wgrad_plan_bf16(SisrWgradDesc *d, int32_t max_pixel_blocks);
+/* wgrad_deep.hip: 3x3, pad 1, stride 1 | 2, Cin % 64 == 0, Cout % 64 == 0, NHWC bf16 operands (x prologue NONE / ACT / AFFINE_ACT,
+ * gradient prologue any of the one- or two-tensor forms).  Call after sisr_wgrad_plan_bf16 (slab layout and sizes are shared with
+ * the generic kernel); on success deep.enabled = 1 and sisr_wgrad_bf16_slabs answers deep.n_pb.  target_wg: 0 = default. */
+int sisr_wgrad_deep_plan(SisrWgradDesc *d, int32_t target_wg);
+/* a fully filled descriptor (operands, modes, storage flags) will run on wgrad_deep.hip */
+int sisr_wgrad_deep_eligible(const SisrWgradDesc *d);
 int sisr_conv2d_wgrad_bf16(const SisrWgradDesc *d, void *stream);
 /* The trunk geometry with bf16 NHWC operands (x prologue NONE / ACT / AFFINE_ACT, gradient prologue BNBWD /
  * BNACT_BWD) runs on the persistent kernel of wgrad_trunk.hip behind sisr_conv2d_wgrad_bf16: one slab per workgroup,
@@ -517,7 +547,7 @@ int sisr_adam_step(const SisrAdamDesc *table_dev, int32_t n, int64_t total_block
                    double eps, double weight_decay, double bias_corr1, double bias_corr2, void *stream);
 
 /* sizeof() of the descriptor structs in declaration order (Conv, Wgrad, Weight, WeightGrad,
- * BnBwd, ConvPlan, DeepPlan) so a binding can verify its mirror of this header; returns the count. */
+ * BnBwd, ConvPlan, DeepPlan, WgradDeepPlan) so a binding can verify its mirror of this header; returns the count. */
 int sisr_struct_sizes(int32_t *out, int32_t cap);
 int sisr_device_info(int32_t *n_cu, int32_t *lds_per_cu, char *arch, int32_t arch_len);
 int sisr_mfma_selftest(float *out_dev /* >= 32*32 floats */, void *stream);

@@ -53,6 +53,12 @@ class ConvDesc(C.Structure):
                 [('wdeep', _f), ('deep_ws', _f), ('epi_scale_p', _f), ('wdeep_c', _f * 4), ('deep_ckh', _i32 * 4), ('deep', DeepPlan)])
 
 
+class WgradDeepPlan(C.Structure):
+    _fields_ = ([(n, _i32) for n in ('enabled', 'TH', 'TW', 'tiles_x', 'tiles_q', 'n_tiles', 'PR', 'IW', 'IH_max', 'IWd', 'IHd_max',
+                                     'NPOS_max', 'XP_max', 'NITX', 'NITD', 'n_pb', 'tiles_per_pb', 'n_cib', 'n_cob', 'lds_bytes', 'slab_bf16')] +
+                [(n, C.c_uint32) for n in ('m_tiles_x', 'm_tw', 'm_ho', 'm_pr', 'm_iw', 'm_iwd')])
+
+
 class WgradDesc(C.Structure):
     _fields_ = ([(n, _f) for n in ('x1', 'x2', 'pa', 'pb', 'pd', 'ps', 'pt',
                                    'g1', 'g2', 'qa', 'qb', 'qd', 'qs', 'qt', 'slab', 'bias_slab')] +
@@ -66,7 +72,7 @@ class WgradDesc(C.Structure):
                                      'grid_x', 'n_slabs', 'slab_elems', 'lds_bytes')] +
                 [(n, C.c_uint32) for n in ('m_tiles_x', 'm_tiles_y', 'm_iw', 'm_twp', 'm_kw')] +
                 [('x_bf16', _i32), ('g_bf16', _i32), ('mfma_split', _i32)] +
-                [('slab_stride', _i64)])
+                [('slab_stride', _i64), ('deep', WgradDeepPlan)])
 
 
 class WeightDesc(C.Structure):
@@ -127,6 +133,8 @@ _SIGS = {
     'sisr_wgrad_toimage_eligible': [C.POINTER(WgradDesc)],
     'sisr_wgrad_toimage_f32_eligible': [C.POINTER(WgradDesc)],
     'sisr_wgrad_plan_bf16': [C.POINTER(WgradDesc), _i32],
+    'sisr_wgrad_deep_plan': [C.POINTER(WgradDesc), _i32],
+    'sisr_wgrad_deep_eligible': [C.POINTER(WgradDesc)],
     'sisr_conv2d_wgrad_bf16': [C.POINTER(WgradDesc), _f],
     'sisr_tr16_selftest': [_f, _f],
     'sisr_slab_reduce_f32': [_f, _f, _i32, _i64, _i64, _f],
@@ -209,10 +217,10 @@ def lib():
     L.sisr_version.argtypes = []
     sizes = (_i32 * 8)()
     n = L.sisr_struct_sizes(sizes, 8)
-    mine = [C.sizeof(t) for t in (ConvDesc, WgradDesc, WeightDesc, WeightGradDesc, BnBwdDesc, ConvPlan, DeepPlan)]
-    if n != 7 or list(sizes[:7]) != mine:
+    mine = [C.sizeof(t) for t in (ConvDesc, WgradDesc, WeightDesc, WeightGradDesc, BnBwdDesc, ConvPlan, DeepPlan, WgradDeepPlan)]
+    if n != 8 or list(sizes[:8]) != mine:
         raise RuntimeError('libsisr_hip.so does not match the Python mirror of sisr_hip.h: %s vs %s'
-                           % (list(sizes[:7]), mine))
+                           % (list(sizes[:8]), mine))
     _lib = L
     return L
 

@@ -91,11 +91,11 @@ extern "C" int sisr_tr16_selftest(short* out_dev, void* stream) {
 }
 
 extern "C" int sisr_struct_sizes(int32_t* out, int32_t cap) {
-    const int32_t v[7] = {(int32_t)sizeof(SisrConvDesc), (int32_t)sizeof(SisrWgradDesc), (int32_t)sizeof(SisrWeightDesc),
+    const int32_t v[8] = {(int32_t)sizeof(SisrConvDesc), (int32_t)sizeof(SisrWgradDesc), (int32_t)sizeof(SisrWeightDesc),
                           (int32_t)sizeof(SisrWeightGradDesc), (int32_t)sizeof(SisrBnBwdDesc),
-                          (int32_t)sizeof(SisrConvPlan), (int32_t)sizeof(SisrDeepPlan)};
-    for (int i = 0; i < 7 && i < cap; ++i) out[i] = v[i];
-    return 7;
+                          (int32_t)sizeof(SisrConvPlan), (int32_t)sizeof(SisrDeepPlan), (int32_t)sizeof(SisrWgradDeepPlan)};
+    for (int i = 0; i < 8 && i < cap; ++i) out[i] = v[i];
+    return 8;
 }
 
 // hipGetLastError() is per host thread and sticky until fetched: a failed stream capture (or any other failed

@@ -273,6 +273,8 @@ extern "C" int sisr_wgrad_trunk_eligible(const SisrWgradDesc* d);
 int sisr_wgrad_trunk_launch(const SisrWgradDesc* d, hipStream_t st);      // wgrad_trunk.hip
 extern "C" int sisr_wgrad_toimage_eligible(const SisrWgradDesc* d);
 int sisr_wgrad_toimage_launch(const SisrWgradDesc* d, hipStream_t st);    // wgrad_toimage.hip
+extern "C" int sisr_wgrad_deep_eligible(const SisrWgradDesc* d);
+int sisr_wgrad_deep_launch(const SisrWgradDesc* d, hipStream_t st);       // wgrad_deep.hip
 
 extern "C" int sisr_conv2d_wgrad_bf16(const SisrWgradDesc* d, void* stream) {
     if (!d || !d->x1 || !d->g1 || !d->slab) return SISR_E_BADARG;
@@ -283,6 +285,7 @@ extern "C" int sisr_conv2d_wgrad_bf16(const SisrWgradDesc* d, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (sisr_wgrad_trunk_eligible(d)) return sisr_wgrad_trunk_launch(d, st);
     if (sisr_wgrad_toimage_eligible(d)) return sisr_wgrad_toimage_launch(d, st);    // the generator's last conv (64 -> 3)
+    if (sisr_wgrad_deep_eligible(d)) return sisr_wgrad_deep_launch(d, st);          // 3x3, channels in 64s
     const int np = 4 / d->NJ, ntap = d->KH * d->KW;
     switch ((ntap + np - 1) / np) {                        // taps per wave
         case 1: return launch_wgrad_bf16<1>(d, st);

@@ -388,6 +388,7 @@ extern "C" int sisr_wgrad_trunk_eligible(const SisrWgradDesc* d) {
 // slabs a launch of this descriptor writes (rows of `slab` at slab_stride): one per workgroup
 extern "C" int sisr_wgrad_toimage_eligible(const SisrWgradDesc* d);
 int sisr_wgrad_toimage_slabs(const SisrWgradDesc* d);                         // wgrad_toimage.hip
+extern "C" int sisr_wgrad_deep_eligible(const SisrWgradDesc* d);               // wgrad_deep.hip
 
 // The persistent kernel writes the gradient part of its slabs as bf16 (231 slabs x 147 KB written and re-read per layer were
 // two thirds of the finishing launch; a partial sum rounded to bf16 costs up to ~2e-3 relative on a cancelling total, inside this
@@ -400,13 +401,16 @@ static bool wtrunk_slab_bf16() {
 // sisr_bn_bwd_finalize_slab); 0: fp32 slabs
 extern "C" int64_t sisr_wgrad_bf16_slab_lead(const SisrWgradDesc* d) {
     if (!d) return 0;
-    return sisr_wgrad_trunk_eligible(d) && wtrunk_slab_bf16() ? (int64_t)d->slab_elems : 0;
+    if (sisr_wgrad_trunk_eligible(d)) return wtrunk_slab_bf16() ? (int64_t)d->slab_elems : 0;
+    if (sisr_wgrad_toimage_eligible(d)) return 0;
+    return sisr_wgrad_deep_eligible(d) && d->deep.slab_bf16 ? (int64_t)d->slab_elems : 0;
 }
 
 extern "C" int sisr_wgrad_bf16_slabs(const SisrWgradDesc* d) {
     if (!d) return SISR_E_BADARG;
     if (sisr_wgrad_trunk_eligible(d)) return wtrunk_grid(d) / (d->Cout == 256 ? 4 : 1);
-    return sisr_wgrad_toimage_eligible(d) ? sisr_wgrad_toimage_slabs(d) : d->n_slabs;
+    if (sisr_wgrad_toimage_eligible(d)) return sisr_wgrad_toimage_slabs(d);
+    return sisr_wgrad_deep_eligible(d) ? d->deep.n_pb : d->n_slabs;
 }
 
 template <int GPRO>

@@ -201,7 +201,8 @@ class ConvGeom:
         (fwd_bf16, dgrad_bf16, wgrad_bf16) tells which kernel family each template was planned for."""
         if max_pixel_blocks is None:
             max_pixel_blocks = int(os.environ.get('SISR_WGRAD_PIXEL_BLOCKS', '512'))      # A/B knob of the wgrad grids
-        key = (n, h, w, PRECISION, storage_bf16(), max_pixel_blocks, os.environ.get('SISR_DEEP', '1'))
+        key = (n, h, w, PRECISION, storage_bf16(), max_pixel_blocks, os.environ.get('SISR_DEEP', '1'), os.environ.get('SISR_WGRAD_DEEP', '1'),
+               os.environ.get('SISR_WGRAD_DEEP_PB', ''))
         if key in self._plans:
             return self._plans[key]
         lib = L.lib()
@@ -251,6 +252,8 @@ class ConvGeom:
             # image padded to 4 channels (conv_wgrad materialises it), 16x the exact-fp32 matrix rate
             g.Cout = (self.cout + 3) // 4 * 4 if self.cout < 32 else self.cout
             g_bf = g.Cout % 4 == 0 and lib.sisr_wgrad_plan_bf16(C.byref(g), max_pixel_blocks) == 0
+            if g_bf and self.k == 3 and self.pad == 1:
+                lib.sisr_wgrad_deep_plan(C.byref(g), 0)               # 3x3, channels in 64s: wgrad_deep.hip (g.deep.enabled)
         if not g_bf:
             g.Cout = self.cout
             L.check(lib.sisr_wgrad_plan(C.byref(g), max_pixel_blocks), 'sisr_wgrad_plan')
@@ -788,6 +791,9 @@ def conv_dgrad(prep, dy_op, res=None, y_mode=L.Y_NHWC, bnb=None):
     return out if bnb is None else (out, part)
 
 
+KERNEL_COUNTS = {}          # launches per kernel family, for the tests that must see a family run (not a timing path: host counters)
+
+
 class PendingSlabs:
     """Slab reductions that have not been launched yet.  conv_wgrad(..., defer=pending) leaves the fixed-order sum of
     its per-workgroup slabs here instead of launching sisr_slab_reduce_f32; the next bn_backward(..., part=rows,
@@ -837,6 +843,8 @@ def conv_wgrad(prep, x_op, dy_op, defer=None):
     dy_op.fill(g, g=True)
     g.mfma_split = mfma_split()
     n_slabs = (lib.sisr_wgrad_bf16_slabs if prep.kinds[2] else lib.sisr_wgrad_f32_slabs)(C.byref(g))
+    if prep.kinds[2] and g.deep.enabled and lib.sisr_wgrad_deep_eligible(C.byref(g)):
+        KERNEL_COUNTS['wgrad_deep'] = KERNEL_COUNTS.get('wgrad_deep', 0) + 1
     lead = int(lib.sisr_wgrad_bf16_slab_lead(C.byref(g))) if prep.kinds[2] else 0     # the persistent bf16 kernel's slabs are bf16
     slab = torch.empty((n_slabs, stride), dtype=torch.float32, device=dev)
     g.slab = slab.data_ptr()

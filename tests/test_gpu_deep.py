@@ -251,3 +251,107 @@ def test_classifier_head_forward_backward(L, shape):
     assert maxrel(dx, xr.grad) < 1e-4
     dw1 = Ef.fc_wgrad_only(d1, xd, w1d)
     assert maxrel(dw1, w1r.grad) < 1e-4
+
+
+# ---- the weight gradient of the same layers (csrc/wgrad_deep.hip) -----------------------------------------------------------------
+WG_SMALL = [
+    (3, 64, 64, 1, 12, 12),        # bands straddling images
+    (5, 64, 128, 1, 6, 6),         # many images per band
+    (2, 64, 128, 1, 24, 24),
+    (2, 128, 64, 1, 16, 32),       # two column tiles
+    (2, 64, 64, 1, 37, 29),        # ragged
+    (3, 64, 128, 2, 24, 24),       # stride 2: parity planes
+    (2, 64, 64, 2, 32, 32),
+    (3, 64, 64, 2, 13, 11),        # stride 2, odd sizes
+    (4, 256, 512, 1, 12, 12),      # 4 x 8 channel blocks
+    (4, 512, 512, 2, 12, 12),      # D's last layer
+]
+
+
+def _wgrad_case(E, L, case, xpro, gpro, seed=0):
+    n, cin, cout, stride, h, w = case
+    p, ref, wt, b, keep = _prep(E, n, cin, cout, stride, h, w, seed)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    bc = lambda v: v[None, :, None, None]
+    slope = 0.2
+    x = _bf(_rand((n, cin, h, w), seed + 31))
+    xd = nhwc(x).cuda().to(torch.bfloat16)
+    if xpro == 'none':
+        x_op, xt = E.Operand.plain(xd), x
+    elif xpro == 'act':
+        x_op, xt = E.Operand(xd, tuple(xd.shape), pro=L.PRO_ACT, slope=slope), _lrelu(x, slope)
+    else:
+        pa, pd = _rand((cin,), seed + 32) * 0.5 + 1.0, _rand((cin,), seed + 33, 0.3)
+        x_op = E.Operand(xd, tuple(xd.shape), pro=L.PRO_AFFINE_ACT, pa=pa.cuda(), pd=pd.cuda(), slope=slope)
+        xt = _lrelu(bc(pa) * x + bc(pd), slope)
+    dy = _bf(_rand((n, cout, ho, wo), seed + 34))
+    c = _bf(_rand((n, cout, ho, wo), seed + 35))
+    dyd, cd = nhwc(dy).cuda().to(torch.bfloat16), nhwc(c).cuda().to(torch.bfloat16)
+    qa, qb, qd = _rand((cout,), seed + 36) * 0.5 + 1.0, _rand((cout,), seed + 37, 0.2), _rand((cout,), seed + 38, 0.1)
+    ks, kt = _rand((cout,), seed + 39) * 0.5 + 1.0, _rand((cout,), seed + 40, 0.3)
+    if gpro == 'none':
+        g_op, g = E.Operand.plain(dyd), dy
+    elif gpro == 'act_bwd':
+        g_op, g = E.Operand(dyd, tuple(dyd.shape), pro=L.PRO_ACT_BWD, x2=cd, slope=slope), torch.where(c > 0, dy, slope * dy)
+    elif gpro == 'bnbwd':
+        g_op = E.Operand(dyd, tuple(dyd.shape), pro=L.PRO_BNBWD, x2=cd, pa=qa.cuda(), pb=qb.cuda(), pd=qd.cuda())
+        g = bc(qa) * dy + bc(qb) * c + bc(qd)
+    else:
+        g_op = E.Operand(dyd, tuple(dyd.shape), pro=L.PRO_BNACT_BWD, x2=cd, pa=qa.cuda(), pb=qb.cuda(), pd=qd.cuda(), ps=ks.cuda(),
+                         pt=kt.cuda(), slope=slope)
+        z = bc(ks) * c + bc(kt)
+        g = bc(qa) * torch.where(z > 0, dy, slope * dy) + bc(qb) * c + bc(qd)
+    gw_ref = torch.nn.grad.conv2d_weight(_bf(xt).double(), (cout, cin, 3, 3), _bf(g).double(), stride=stride, padding=1)
+    return p, ref, x_op, g_op, gw_ref, g.double()
+
+
+def _run_wgrad(E, p, ref, x_op, g_op):
+    before = E.KERNEL_COUNTS.get('wgrad_deep', 0)
+    red = E.conv_wgrad(p, x_op, g_op)
+    assert E.KERNEL_COUNTS.get('wgrad_deep', 0) == before + 1, 'the descriptor did not run on wgrad_deep.hip'
+    wg = E.WeightGradBatch()
+    wg.add(p, red)
+    return wg.run()[id(ref)]
+
+
+@pytest.mark.parametrize('pros', [('none', 'none'), ('act', 'act_bwd'), ('affine_act', 'bnact_bwd'), ('affine_act', 'bnbwd')])
+@pytest.mark.parametrize('case', WG_SMALL)
+def test_weight_gradient_prologues_and_bias(E, L, case, pros):
+    """dW = sum_p x'(p * s + tap - 1) (x) dy'(p) with both operands lazy (x: BatchNorm apply + LeakyReLU of the layer in front, dy: the
+    activation / BatchNorm backward of the layer itself, model_discriminator.py:5-15 differentiated); bias gradient = sum of dy'"""
+    p, ref, x_op, g_op, gw_ref, g = _wgrad_case(E, L, case, *pros)
+    assert p.plans[2].deep.enabled == 1
+    gw, gb = _run_wgrad(E, p, ref, x_op, g_op)
+    assert maxrel(gw, gw_ref) < TOL, 'weight gradient'
+    l1 = g.abs().sum(dim=(0, 2, 3))
+    assert float(((gb.double().cpu() - g.sum(dim=(0, 2, 3))).abs() / l1.clamp_min(1e-30)).max()) < 2e-3, 'bias gradient'
+    gw2, gb2 = _run_wgrad(E, p, ref, x_op, g_op)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2), 'fixed-order slab reduction: bitwise repeatable'
+
+
+def test_weight_gradient_fp32_slabs_and_pixel_block_counts(E, L, monkeypatch):
+    """SISR_SLAB_BF16=0 keeps fp32 slabs; the result may not depend on how the tiles are split into pixel blocks beyond rounding"""
+    case = (3, 64, 128, 2, 24, 24)
+    outs = []
+    for env in ({'SISR_SLAB_BF16': '0'}, {'SISR_SLAB_BF16': '0', 'SISR_WGRAD_DEEP_PB': '1'}, {'SISR_WGRAD_DEEP_PB': '7'}):
+        for k in ('SISR_SLAB_BF16', 'SISR_WGRAD_DEEP_PB'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p, ref, x_op, g_op, gw_ref, g = _wgrad_case(E, L, case, 'affine_act', 'bnact_bwd')
+        if 'SISR_WGRAD_DEEP_PB' in env:
+            assert p.plans[2].deep.n_pb <= int(env['SISR_WGRAD_DEEP_PB'])           # (rounded to whole tiles per block)
+        gw, gb = _run_wgrad(E, p, ref, x_op, g_op)
+        assert maxrel(gw, gw_ref) < (1e-3 if 'SISR_SLAB_BF16' in env else TOL)
+        outs.append(gw)
+    assert maxrel(outs[0], outs[1]) < 1e-5
+
+
+@pytest.mark.parametrize('case', _d_layers(96) + [(16, 64, 64, 1, 24, 24)])
+def test_full_size_layers_weight_gradient(E, L, case):
+    """the discriminator's seven 3x3 layers at 96 x 96, B = 16, and the generator's trunk layer at a 24 x 24 input"""
+    p, ref, x_op, g_op, gw_ref, g = _wgrad_case(E, L, case, 'affine_act', 'bnact_bwd')
+    gw, gb = _run_wgrad(E, p, ref, x_op, g_op)
+    assert maxrel(gw, gw_ref) < TOL
+    l1 = g.abs().sum(dim=(0, 2, 3))
+    assert float(((gb.double().cpu() - g.sum(dim=(0, 2, 3))).abs() / l1.clamp_min(1e-30)).max()) < 2e-3

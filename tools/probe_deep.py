@@ -1,6 +1,7 @@
 """launch times of the conv_deep.hip layers at the shapes of BASELINE's configs (B16): forward (ACT prologue, statistics) and data
 gradient (BNACT_BWD prologue, fused reductions), HIP events on the launch stream.  Environment knobs are read per process:
 SISR_DEEP=0 (generic kernel), SISR_DEEP_BN=64, SISR_DEEP_TARGET=<workgroups>, SISR_DEEP_MINCPS=<chunks>.
+SISR_WGRAD_DEEP=0 (generic weight-gradient kernel), SISR_WGRAD_DEEP_PB=<pixel blocks>.
 usage: python tools/probe_deep.py [hr96|hr192|all]"""
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
@@ -49,7 +50,7 @@ def timeit(fn, iters=20, reps=5):
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'hr96'
 for hr in ([96] if which == 'hr96' else [192] if which == 'hr192' else [96, 192]):
-    print('--- B16, HR %d   (knobs: %s)' % (hr, {k: v for k, v in os.environ.items() if k.startswith('SISR_DEEP')}))
+    print('--- B16, HR %d   (knobs: %s)' % (hr, {k: v for k, v in os.environ.items() if k.startswith('SISR_DEEP') or k.startswith('SISR_WGRAD')}))
     for net, cin, cout, st, h, w in layers(hr):
         n = 16
         wt = (torch.rand(cout, cin, 3, 3, device='cuda') - 0.5) * 0.05
@@ -74,5 +75,11 @@ for hr in ([96] if which == 'hr96' else [192] if which == 'hr192' else [96, 192]
         op = E.Operand(dy, tuple(dy.shape), pro=L.PRO_BNACT_BWD, x2=c, pa=q[0], pb=q[1], pd=q[2], ps=q[3], pt=q[4], slope=0.01)
         fuse = E.can_fuse_bn_backward(p)
         t_d = timeit(lambda: E.conv_dgrad(p, op, bnb=(xb, k4, 0.01) if fuse else None))
-        print('%s %3d->%3d s%d %3dx%-3d  fwd %7.1f us %6.0f TF   dgrad %7.1f us %6.0f TF   %.1f GF  %s' %
-              (net, cin, cout, st, h, w, t_f, flops / t_f / 1e6, t_d, flops / t_d / 1e6, flops / 1e9, info))
+        t_w = float('nan')
+        if net != 'V':                                  # (the VGG extractor has no weight gradient)
+            xop = E.Operand(x, tuple(x.shape), pro=L.PRO_AFFINE_ACT, pa=k4[0], pd=k4[1], slope=0.01)
+            t_w = timeit(lambda: E.conv_wgrad(p, xop, op))        # kernel + its slab reduction
+            wp = p.plans[2].deep
+            info += '  wgrad: %s' % ('deep tiles %d pb %d wgs %d' % (wp.n_tiles, wp.n_pb, wp.n_pb * wp.n_cib * wp.n_cob) if wp.enabled else 'generic')
+        print('%s %3d->%3d s%d %3dx%-3d  fwd %7.1f us %6.0f TF   dgrad %7.1f us %6.0f TF   wgrad %7.1f us %6.0f TF   %.1f GF  %s' %
+              (net, cin, cout, st, h, w, t_f, flops / t_f / 1e6, t_d, flops / t_d / 1e6, t_w, flops / t_w / 1e6, flops / 1e9, info))
