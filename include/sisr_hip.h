@@ -188,6 +188,7 @@ typedef struct SisrWgradDeepPlan {
     int32_t n_cib, n_cob;           /* 64-channel blocks of Cin / Cout                                           */
     int32_t lds_bytes;
     int32_t slab_bf16;              /* the gradient part of a slab row is bf16 (sisr_wgrad_bf16_slab_lead)       */
+    int32_t batch_first_wg;         /* sisr_wgrad_deep_batch: first flat workgroup index of this member (0 alone) */
     uint32_t m_tiles_x, m_tw, m_ho, m_pr, m_iw, m_iwd;
 } SisrWgradDeepPlan;
 
@@ -268,6 +269,11 @@ int sisr_wgrad_plan_bf16(SisrWgradDesc *d, int32_t max_pixel_blocks);
 int sisr_wgrad_deep_plan(SisrWgradDesc *d, int32_t target_wg);
 /* a fully filled descriptor (operands, modes, storage flags) will run on wgrad_deep.hip */
 int sisr_wgrad_deep_eligible(const SisrWgradDesc *d);
+/* Several wgrad_deep.hip layers in one launch (grid z = layer): table_host = n fully filled, eligible descriptors of one stride, all
+ * with or all without a two-tensor gradient prologue; table_dev = the same bytes in device memory.  Plan each member with its share
+ * of the chip as target_wg (sisr_wgrad_deep_plan): the batch then walks 3-4 times as many tiles per workgroup behind the same fixed
+ * costs and writes a third of the slabs.  Results per layer are those of sisr_conv2d_wgrad_bf16 on the same plan. */
+int sisr_wgrad_deep_batch(const SisrWgradDesc *table_host, const SisrWgradDesc *table_dev, int32_t n, void *stream);
 int sisr_conv2d_wgrad_bf16(const SisrWgradDesc *d, void *stream);
 /* The trunk geometry with bf16 NHWC operands (x prologue NONE / ACT / AFFINE_ACT, gradient prologue BNBWD /
  * BNACT_BWD) runs on the persistent kernel of wgrad_trunk.hip behind sisr_conv2d_wgrad_bf16: one slab per workgroup,
@@ -294,6 +300,11 @@ int sisr_wgrad_toimage_f32_eligible(const SisrWgradDesc *d);
 int sisr_conv2d_wgrad_f32(const SisrWgradDesc *d, void *stream);
 /* out[i] = sum_s slab[s][i], i < elems (also used for the bias slabs) */
 int sisr_slab_reduce_f32(const float *slab, float *out, int32_t n_slabs, int64_t elems, int64_t lead_bf16, void *stream);
+/* n_jobs independent reductions (arrays of n_jobs entries each, HOST memory: the jobs travel in the kernel arguments, eight per
+ * launch) -- the weight gradients of one backward pass are summed by one launch instead of one per layer.  Same arithmetic and
+ * order per job as sisr_slab_reduce_f32: bit-identical results. */
+int sisr_slab_reduce_multi(const void *const *slabs, void *const *outs, const int32_t *n_slabs, const int64_t *elems,
+                           const int64_t *lead_bf16, int32_t n_jobs, void *stream);
 /* lead_bf16: the first lead_bf16 elements of every row are stored as bf16 at the row's start (what the persistent bf16
  * weight-gradient kernel writes: sisr_wgrad_bf16_slab_lead(d)), the rest -- the bias partials -- as fp32 at their float offset; 0: fp32 rows */
 int64_t sisr_wgrad_bf16_slab_lead(const SisrWgradDesc *d);
@@ -514,7 +525,8 @@ int sisr_act_bwd(const float *dy, const float *ref, float *out, int64_t n, int32
  * 22-bit fixed-point coefficients, rounding to uint8 after each pass), uint8 -> float32 / 255, (t - mean) / std.
  * Integer arithmetic throughout the resize: bit-exact with Pillow.
  * sisr_resize_coeffs: HOST function; returns the taps per output index (ksize) and, with non-NULL tables, fills
- *   bounds[out_size][2] = (first input index, tap count) and kk[out_size][ksize] for one axis.
+ *   bounds[out_size][2] = (first input index, tap count) and kk[out_size][ksize] for one axis.  ksize > 64 (a down-scale
+ *   above ~31x) is SISR_E_UNSUPPORTED in BOTH call modes, so the size query already refuses what the fill would.
  * sisr_resize_u8_normalize: src [N][H0][W0][C] uint8 -> dst [N][C][H][W] float32 with device copies of the two tables. */
 int sisr_resize_coeffs(int32_t in_size, int32_t out_size, int32_t *bounds, int32_t *kk);
 int sisr_resize_u8_normalize(const unsigned char *src, float *dst, int32_t N, int32_t H0, int32_t W0, int32_t C,

@@ -55,7 +55,7 @@ class ConvDesc(C.Structure):
 
 class WgradDeepPlan(C.Structure):
     _fields_ = ([(n, _i32) for n in ('enabled', 'TH', 'TW', 'tiles_x', 'tiles_q', 'n_tiles', 'PR', 'IW', 'IH_max', 'IWd', 'IHd_max',
-                                     'NPOS_max', 'XP_max', 'NITX', 'NITD', 'n_pb', 'tiles_per_pb', 'n_cib', 'n_cob', 'lds_bytes', 'slab_bf16')] +
+                                     'NPOS_max', 'XP_max', 'NITX', 'NITD', 'n_pb', 'tiles_per_pb', 'n_cib', 'n_cob', 'lds_bytes', 'slab_bf16', 'batch_first_wg')] +
                 [(n, C.c_uint32) for n in ('m_tiles_x', 'm_tw', 'm_ho', 'm_pr', 'm_iw', 'm_iwd')])
 
 
@@ -135,9 +135,11 @@ _SIGS = {
     'sisr_wgrad_plan_bf16': [C.POINTER(WgradDesc), _i32],
     'sisr_wgrad_deep_plan': [C.POINTER(WgradDesc), _i32],
     'sisr_wgrad_deep_eligible': [C.POINTER(WgradDesc)],
+    'sisr_wgrad_deep_batch': [C.POINTER(WgradDesc), _f, _i32, _f],
     'sisr_conv2d_wgrad_bf16': [C.POINTER(WgradDesc), _f],
     'sisr_tr16_selftest': [_f, _f],
     'sisr_slab_reduce_f32': [_f, _f, _i32, _i64, _i64, _f],
+    'sisr_slab_reduce_multi': [_f, _f, _f, _f, _f, _i32, _f],
     'sisr_wgrad_bf16_slab_lead': [C.POINTER(WgradDesc)],
     'sisr_weights_prepare': [_f, _i32, _i32, _i32, _f],
     'sisr_weights_sn': [_f, _i32, _i32, _i32, _f],

@@ -177,6 +177,27 @@ __global__ void __launch_bounds__(SISR_BLOCK) slab_reduce_kernel(const float* __
     slab_reduce_block(slab, out, n_slabs, elems, blockIdx.x, sh, lead);
 }
 
+// several independent reductions in ONE launch (the weight gradients of one backward pass through the discriminator: seven slab
+// sets that are all final before the un-packing launch needs any of them); the jobs travel in the kernel arguments
+#define SR_MAX_JOBS 8
+struct SlabJobs {
+    const float* slab[SR_MAX_JOBS];
+    float* out[SR_MAX_JOBS];
+    int64_t elems[SR_MAX_JOBS], lead[SR_MAX_JOBS];
+    int n_slabs[SR_MAX_JOBS];
+    int first_block[SR_MAX_JOBS + 1];
+    int n;
+};
+__global__ void __launch_bounds__(SISR_BLOCK) slab_reduce_multi_kernel(const SlabJobs j) {
+    __shared__ f32x4 sh[SR_SPLITS][SR_COLS];
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < SR_MAX_JOBS; ++i) k += (i < j.n && (int)blockIdx.x >= j.first_block[i]) ? 1 : 0;
+    // (uniform per workgroup: a job is served by one form or the other, see sisr_slab_reduce_multi's block counts)
+    if (j.n_slabs[k] <= SR_SPLITS) slab_reduce_block_few(j.slab[k], j.out[k], j.n_slabs[k], j.elems[k], (int)blockIdx.x - j.first_block[k], j.lead[k]);
+    else slab_reduce_block(j.slab[k], j.out[k], j.n_slabs[k], j.elems[k], (int)blockIdx.x - j.first_block[k], sh, j.lead[k]);
+}
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 extern "C" int sisr_wgrad_plan(SisrWgradDesc* d, int32_t max_pixel_blocks) {
@@ -282,5 +303,30 @@ extern "C" int sisr_slab_reduce_f32(const float* slab, float* out, int32_t n_sla
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(SISR_BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
                        slab, out, n_slabs, elems, lead_bf16);
     SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_slab_reduce_multi(const void* const* slabs, void* const* outs, const int32_t* n_slabs, const int64_t* elems,
+                                      const int64_t* leads, int32_t n_jobs, void* stream) {
+    if (!slabs || !outs || !n_slabs || !elems || !leads || n_jobs <= 0) return SISR_E_BADARG;
+    for (int i0 = 0; i0 < n_jobs; i0 += SR_MAX_JOBS) {
+        SlabJobs j;
+        std::memset(&j, 0, sizeof(j));
+        j.n = std::min(SR_MAX_JOBS, n_jobs - i0);
+        int blocks = 0;
+        for (int k = 0; k < j.n; ++k) {
+            const int i = i0 + k;
+            if (!slabs[i] || !outs[i] || n_slabs[i] <= 0 || elems[i] <= 0) return SISR_E_BADARG;
+            if ((elems[i] & 3) || (leads[i] & 3) || leads[i] < 0 || leads[i] > elems[i]) return SISR_E_BADARG;
+            j.slab[k] = static_cast<const float*>(slabs[i]); j.out[k] = static_cast<float*>(outs[i]);
+            j.n_slabs[k] = n_slabs[i]; j.elems[k] = elems[i]; j.lead[k] = leads[i];
+            j.first_block[k] = blocks;
+            const int cols = n_slabs[i] <= SR_SPLITS ? SR_FEW_COLS : SR_COLS;
+            blocks += (int)((elems[i] / 4 + cols - 1) / cols);
+        }
+        j.first_block[j.n] = blocks;
+        hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(blocks), dim3(SISR_BLOCK), 0, reinterpret_cast<hipStream_t>(stream), j);
+        SISR_CHECK_LAUNCH();
+    }
     return 0;
 }

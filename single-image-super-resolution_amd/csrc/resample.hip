@@ -158,6 +158,7 @@ extern "C" int sisr_resize_coeffs(int32_t in_size, int32_t out_size, int32_t* bo
     const double filterscale = scale < 1.0 ? 1.0 : scale;
     const double support = 1.0 * filterscale;
     const int ksize = (int)ceil(support) * 2 + 1;
+    if (ksize > 64) return SISR_E_UNSUPPORTED;            // (a down-scale above ~31x; checked in the size query too, before a caller sizes tables)
     if (!bounds || !kk) return ksize;
     const double ss = 1.0 / filterscale;
     for (int xx = 0; xx < out_size; ++xx) {
@@ -168,7 +169,6 @@ extern "C" int sisr_resize_coeffs(int32_t in_size, int32_t out_size, int32_t* bo
         if (xmax > in_size) xmax = in_size;
         xmax -= xmin;
         double w[64], ww = 0.0;
-        if (ksize > 64) return SISR_E_UNSUPPORTED;
         for (int x = 0; x < xmax; ++x) {
             double a = (x + xmin - center + 0.5) * ss;
             if (a < 0.0) a = -a;

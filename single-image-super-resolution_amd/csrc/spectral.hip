@@ -11,6 +11,8 @@
 
 #include <algorithm>
 
+#include "sisr_bf16_stage.h"
+
 #define SN_EPS 1e-12f
 
 // Power iteration in four short multi-tensor launches (grid = (weights, jobs); surplus workgroups exit), so
@@ -35,6 +37,21 @@ __global__ void __launch_bounds__(SISR_BLOCK) sn_wt_u_kernel(const SisrWeightDes
     const int r0 = rb * SN_RB, nr = min(SN_RB, rows - r0);
     if (threadIdx.x < nr) us[threadIdx.x] = w.u[r0 + threadIdx.x];
     __syncthreads();
+    if ((cols & 3) == 0 && nr == SN_RB) {
+        // whole row block, rows of whole float4s: a thread owns four consecutive columns and has all 16 rows' loads in flight at
+        // once (the scalar loop below waits for each row before it asks for the next: the phase was latency-bound at 31 us)
+        const int j = cb * SN_CB + threadIdx.x * 4;
+        if (j >= cols) return;
+        const float* wp = w.w_orig + (int64_t)r0 * cols + j;
+        f32x4 v[SN_RB];
+#pragma unroll
+        for (int i = 0; i < SN_RB; ++i) v[i] = *reinterpret_cast<const f32x4*>(wp + (int64_t)i * cols);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < SN_RB; ++i) a += v[i] * us[i];             // row order, as the scalar path: same bits
+        *reinterpret_cast<f32x4*>(w.sn_work + (int64_t)rb * cols + j) = a;
+        return;
+    }
     float acc[SN_CB / SISR_BLOCK];
 #pragma unroll
     for (int k = 0; k < SN_CB / SISR_BLOCK; ++k) acc[k] = 0.f;
@@ -77,7 +94,20 @@ __global__ void __launch_bounds__(SISR_BLOCK) sn_w_v_kernel(const SisrWeightDesc
     const float* wr = w.w_orig + (int64_t)i * cols;
     const float* vec = w.training ? w.sn_work : w.v;
     float a = 0.f;
-    for (int j = lane; j < cols; j += 64) a += wr[j] * vec[j];
+    // twelve loads of each operand in flight per round; the adds keep the order of the plain loop (j = lane, lane + 64, ...), so the
+    // result is bit-identical to it (the plain loop waited for every load before asking for the next: 72 dependent rounds for the
+    // discriminator's 4,608 columns)
+    for (int j0 = lane; j0 < cols; j0 += 64 * 12) {
+        float wv[12], vv[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int jj = min(j0 + 64 * k, cols - 1);
+            wv[k] = wr[jj]; vv[k] = vec[jj];
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            if (j0 + 64 * k < cols) a += wv[k] * vv[k];
+    }
     a = wave_sum(a);
     if (lane == 0) w.sn_work[(int64_t)sn_rblocks(rows) * cols + i] = a;
 }
@@ -350,40 +380,53 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_pack_deep_kernel(const Sis
     if (cb * 32 >= w.Cout || kb * 32 >= w.Cin || w.KH != 3 || w.KW != 3) return;
     const float sc = w.wdp_scaled ? 1.f / (w.sigma ? w.sigma[0] : 1.f) : 1.f;
     const int tid = threadIdx.x;
-    for (int i = tid; i < 32 * 288; i += SISR_BLOCK) {
-        const int co = i / 288, e = i - co * 288;
-        tile[co][e] = w.w_orig[((int64_t)(cb * 32 + co) * w.Cin + kb * 32) * 9 + e] * sc;
+    // 32 couts x 288 contiguous floats (32 ci x 9 taps; 1,152-byte rows: 16-byte aligned), one float4 per item
+    for (int i = tid; i < 32 * 72; i += SISR_BLOCK) {
+        const int co = i / 72, e4 = i - co * 72;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w.w_orig + ((int64_t)(cb * 32 + co) * w.Cin + kb * 32) * 9 + e4 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[co][e4 * 4 + j] = v[j] * sc;
     }
     __syncthreads();
-    const int RW = 3 * 32 + 8;
+    // every image row is written in 16-byte items of 8 bf16: 8 consecutive channels of one tap column (or the 8 padding slots)
+    auto pack8 = [](const float (&v)[8]) {
+        return u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    };
+    constexpr int RW = 3 * 32 + 8, G8 = RW / 8;
     if (w.wdp_fwd) {
         // rows (ky, co) of chunk kb: element kx * 32 + ci = tile[co][ci][ky][kx]
         __bf16* dst = reinterpret_cast<__bf16*>(w.wdp_fwd);
-        for (int i = tid; i < 3 * 32 * RW; i += SISR_BLOCK) {
-            const int row = i / RW, k = i - row * RW, ky = row >> 5, co = row & 31;
-            const float v = k < 96 ? tile[co][(k & 31) * 9 + ky * 3 + (k >> 5)] : 0.f;
-            dst[((int64_t)(kb * 3 + ky) * w.Cout + cb * 32 + co) * RW + k] = (__bf16)v;
+        for (int i = tid; i < 3 * 32 * G8; i += SISR_BLOCK) {
+            const int row = i / G8, k8 = i - row * G8, ky = row >> 5, co = row & 31;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = k8 < 12 ? tile[co][((k8 & 3) * 8 + j) * 9 + ky * 3 + (k8 >> 2)] : 0.f;
+            *reinterpret_cast<u32x4*>(dst + ((int64_t)(kb * 3 + ky) * w.Cout + cb * 32 + co) * RW + k8 * 8) = pack8(v);
         }
     }
     if (w.wdp_dgrad) {
         // conv over dy: chunk = cb (over the forward couts), rows (ky', op = ci), element kx' * 32 + co = tile[co][ci][2 - ky'][2 - kx']
         __bf16* dst = reinterpret_cast<__bf16*>(w.wdp_dgrad);
-        for (int i = tid; i < 3 * 32 * RW; i += SISR_BLOCK) {
-            const int row = i / RW, k = i - row * RW, ky = row >> 5, ci = row & 31;
-            const float v = k < 96 ? tile[k & 31][ci * 9 + (2 - ky) * 3 + (2 - (k >> 5))] : 0.f;
-            dst[((int64_t)(cb * 3 + ky) * w.Cin + kb * 32 + ci) * RW + k] = (__bf16)v;
+        for (int i = tid; i < 3 * 32 * G8; i += SISR_BLOCK) {
+            const int row = i / G8, k8 = i - row * G8, ky = row >> 5, ci = row & 31;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = k8 < 12 ? tile[(k8 & 3) * 8 + j][ci * 9 + (2 - ky) * 3 + (2 - (k8 >> 2))] : 0.f;
+            *reinterpret_cast<u32x4*>(dst + ((int64_t)(cb * 3 + ky) * w.Cin + kb * 32 + ci) * RW + k8 * 8) = pack8(v);
         }
     }
     for (int cls = 0; cls < 4; ++cls) {
         __bf16* dst = reinterpret_cast<__bf16*>(w.wdp_dcls[cls]);
         if (dst == nullptr) continue;
-        const int KHc = w.c_KH[cls], KWc = w.c_KW[cls], RWc = (w.wdp_cls_kw ? w.wdp_cls_kw : KWc) * 32 + 8;
-        for (int i = tid; i < KHc * 32 * RWc; i += SISR_BLOCK) {
-            const int row = i / RWc, k = i - row * RWc, rp = row >> 5, ci = row & 31;
-            const int r = w.c_R0y[cls] - 2 * rp, sx = w.c_R0x[cls] - 2 * (k >> 5);
-            float v = 0.f;
-            if (k < KWc * 32 && r >= 0 && r < 3 && sx >= 0 && sx < 3) v = tile[k & 31][ci * 9 + r * 3 + sx];
-            dst[((int64_t)(cb * KHc + rp) * w.Cin + kb * 32 + ci) * RWc + k] = (__bf16)v;
+        const int KHc = w.c_KH[cls], KWc = w.c_KW[cls], RWc = (w.wdp_cls_kw ? w.wdp_cls_kw : KWc) * 32 + 8, G8c = RWc >> 3;
+        for (int i = tid; i < KHc * 32 * G8c; i += SISR_BLOCK) {
+            const int row = i / G8c, k8 = i - row * G8c, rp = row >> 5, ci = row & 31;
+            const int r = w.c_R0y[cls] - 2 * rp, sx = w.c_R0x[cls] - 2 * (k8 >> 2);
+            const bool ok = k8 < KWc * 4 && r >= 0 && r < 3 && sx >= 0 && sx < 3;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ok ? tile[(k8 & 3) * 8 + j][ci * 9 + r * 3 + sx] : 0.f;
+            *reinterpret_cast<u32x4*>(dst + ((int64_t)(cb * KHc + rp) * w.Cin + kb * 32 + ci) * RWc + k8 * 8) = pack8(v);
         }
     }
 }
@@ -538,22 +581,35 @@ __global__ void __launch_bounds__(SISR_BLOCK) weights_grad_fast_kernel(const Sis
     float part = 0.f;
     if (w.grad != nullptr) {
         const float inv = w.u_used != nullptr ? 1.f / w.sigma[0] : 1.f;
-        // packed rows (tap, ci) of chunk kb: dwpk[((kb * 9 + tap) * 32 + ci) * CoutPad + cb * 32 + c]
+        // packed rows (tap, ci) of chunk kb: dwpk[((kb * 9 + tap) * 32 + ci) * CoutPad + cb * 32 + c]; CoutPad % 32 == 0 here
+        // (the caller's dispatch rule), so a row's 32 couts are eight aligned float4s
         const float* src = w.dwpk + (int64_t)kb * 288 * w.CoutPad + cb * 32;
-        for (int i = tid; i < 288 * 32; i += SISR_BLOCK) {
-            const int row = i >> 5, c = i & 31;
-            tile[row][c] = (cb * 32 + c < w.CoutPad) ? src[(int64_t)row * w.CoutPad + c] : 0.f;
+        const bool full = cb * 32 + 32 <= w.CoutPad;
+        for (int i = tid; i < 288 * 8; i += SISR_BLOCK) {
+            const int row = i >> 3, c4 = i & 7;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (full) v = *reinterpret_cast<const f32x4*>(src + (int64_t)row * w.CoutPad + c4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[row][c4 * 4 + j] = v[j];
         }
         __syncthreads();
-        // OIHW rows: grad[co][kb * 32 + ci][tap], 288 contiguous floats per cout; element e = ci * 9 + tap <- tile[tap * 32 + ci][co]
-        for (int i = tid; i < 32 * 288; i += SISR_BLOCK) {
-            const int co = i / 288, e = i - co * 288;
+        // OIHW rows: grad[co][kb * 32 + ci][tap], 288 contiguous floats per cout (1,152-byte rows); element e = ci * 9 + tap
+        // <- tile[tap * 32 + ci][co]; one float4 of the row per item
+        for (int i = tid; i < 32 * 72; i += SISR_BLOCK) {
+            const int co = i / 72, e4 = i - co * 72;
             if (cb * 32 + co >= w.Cout) continue;
-            const int ci = e / 9, tap = e - ci * 9;
-            const float g = tile[tap * 32 + ci][co];
-            const int64_t o = ((int64_t)(cb * 32 + co) * w.Cin + kb * 32) * 9 + e;
-            if (w.u_used != nullptr) part += g * w.w_orig[o];
-            w.grad[o] = g * inv;
+            const int64_t o = ((int64_t)(cb * 32 + co) * w.Cin + kb * 32) * 9 + e4 * 4;
+            f32x4 g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = e4 * 4 + j, ci = e / 9, tap = e - ci * 9;
+                g[j] = tile[tap * 32 + ci][co];
+            }
+            if (w.u_used != nullptr) {
+                const f32x4 wo = *reinterpret_cast<const f32x4*>(w.w_orig + o);
+                part += (g[0] * wo[0] + g[1] * wo[1]) + (g[2] * wo[2] + g[3] * wo[3]);
+            }
+            *reinterpret_cast<f32x4*>(w.grad + o) = g * inv;
         }
     }
     const float tot = block_sum(part, scratch);

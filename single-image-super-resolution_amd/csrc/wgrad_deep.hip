@@ -96,13 +96,11 @@ struct WdTile {
 
 // S: stride.  NITX / NITD: 16-byte staging items per producer thread (x halo, dy positions).  TWO: two-tensor dy prologue.
 template <int S, int NITX, int NITD, bool TWO>
-__global__ void __launch_bounds__(WD_THREADS, 1) wgrad_deep_kernel(const SisrWgradDesc d) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+__device__ __forceinline__ void wgrad_deep_body(const SisrWgradDesc& d, unsigned char* lds, int blk, int pblk) {
     const SisrWgradDeepPlan& p = d.deep;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cib = (int)blockIdx.x / p.n_cob, cob = (int)blockIdx.x - cib * p.n_cob;
-    const int pblk = blockIdx.y;
+    const int cib = blk / p.n_cob, cob = blk - cib * p.n_cob;
     const int t_begin = pblk * p.tiles_per_pb, ntile = min(p.n_tiles, t_begin + p.tiles_per_pb) - t_begin;
     const int XH = p.XP_max * WD_PSB, DH = p.NPOS_max * WD_PSB;      // bytes of one 32-channel half image
     const int BUF = 2 * (XH + DH);
@@ -336,6 +334,29 @@ __global__ void __launch_bounds__(WD_THREADS, 1) wgrad_deep_kernel(const SisrWgr
     }
 }
 
+template <int S, int NITX, int NITD, bool TWO>
+__global__ void __launch_bounds__(WD_THREADS, 1) wgrad_deep_kernel(const SisrWgradDesc d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    wgrad_deep_body<S, NITX, NITD, TWO>(d, lds, blockIdx.x, blockIdx.y);
+}
+
+// several layers in ONE launch (a flat grid over the members' workgroups): at 96 x 96 a layer alone gives each of its ~150-250 workgroups four tiles -- 15 us of
+// prologue and slab stores around 6 us of work.  A batch plans every member for its SHARE of the chip (sisr_wgrad_deep_plan's
+// target_wg), so a workgroup walks 3-4 times as many tiles behind the same fixed costs and the batch writes a third of the slabs.
+// The weight gradients of a backward pass have no consumer before the optimizer step, so the caller is free to collect them.
+template <int S, int NITX, int NITD, bool TWO>
+__global__ void __launch_bounds__(WD_THREADS, 1) wgrad_deep_table_kernel(const SisrWgradDesc* __restrict__ table, int n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // member of this workgroup: the last one whose first flat index is not beyond it (a 3-D grid sized for the largest member would
+    // launch ~60 empty 512-thread workgroups per real one: measured 530 us for 256 workgroups of work)
+    int z = 0;
+    for (int i = 1; i < n; ++i) z = (int)blockIdx.x >= table[i].deep.batch_first_wg ? i : z;
+    const SisrWgradDesc& d = table[z];
+    const int local = (int)blockIdx.x - d.deep.batch_first_wg, blocks = d.deep.n_cib * d.deep.n_cob;
+    const int pblk = local / blocks;
+    wgrad_deep_body<S, NITX, NITD, TWO>(d, lds, local - pblk * blocks, pblk);
+}
+
 // ---- host -----------------------------------------------------------------------------------------------------------------------
 static bool wd_slab_bf16() {
     const char* e = getenv("SISR_SLAB_BF16");
@@ -407,8 +428,9 @@ extern "C" int sisr_wgrad_deep_plan(SisrWgradDesc* d, int32_t target_wg) {
     if (p.lds_bytes > 160 * 1024 || p.lds_bytes < WD_PROD * 8 * 4) return SISR_E_UNSUPPORTED;
     if (p.IH_max * p.IW >= 65536 || p.NPOS_max >= 65536) return SISR_E_TOOBIG;
     p.n_cib = d->Cin / 64; p.n_cob = d->Cout / 64;
-    // pixel blocks (= slabs): each workgroup walks ceil(n_tiles / n_pb) tiles (~1.5 us each + ~4 us of prologue and slab
-    // stores) in ceil(workgroups / 256) rounds; every slab is written once and re-read once by the reduction
+    // pixel blocks (= slabs): each workgroup walks ceil(n_tiles / n_pb) tiles (measured ~3.5 us each with the chip full: the staging
+    // loads of 256 workgroups run at ~4 TB/s; + ~8 us of prologue and slab stores) in ceil(workgroups / 256) rounds; every slab is
+    // written once and re-read once by the reduction
     p.slab_bf16 = wd_slab_bf16() ? 1 : 0;
     {
         const int blocks = p.n_cib * p.n_cob;
@@ -421,7 +443,7 @@ extern "C" int sisr_wgrad_deep_plan(SisrWgradDesc* d, int32_t target_wg) {
             const int real = (p.n_tiles + tp - 1) / tp;
             if (real != npb) continue;
             const int rounds = (blocks * npb + 255) / 256;
-            const double t = rounds * (tp * 1.5 + 4.0) + npb * slab_us;
+            const double t = rounds * (tp * 3.5 + 8.0) + npb * slab_us;
             if (bt < 0 || t < bt) { bt = t; bpb = npb; }
         }
         if (const char* e = getenv("SISR_WGRAD_DEEP_PB")) {
@@ -479,4 +501,46 @@ int sisr_wgrad_deep_launch(const SisrWgradDesc* d, hipStream_t st) {
     }
     if (p.NITX > 10 || p.NITD > 3) return SISR_E_BADARG;
     return launch_wd<2, 10, 3>(d, st);
+}
+
+template <int S, int NITX, int NITD>
+static int launch_wd_table(const SisrWgradDesc* table_dev, int n, dim3 grid, int lds_bytes, bool two, hipStream_t st) {
+    if (two) {
+        static SisrLdsCap cap;
+        if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&wgrad_deep_table_kernel<S, NITX, NITD, true>), lds_bytes, 0)) return e;
+        hipLaunchKernelGGL((wgrad_deep_table_kernel<S, NITX, NITD, true>), grid, dim3(WD_THREADS), lds_bytes, st, table_dev, n);
+    } else {
+        static SisrLdsCap cap;
+        if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&wgrad_deep_table_kernel<S, NITX, NITD, false>), lds_bytes, 0)) return e;
+        hipLaunchKernelGGL((wgrad_deep_table_kernel<S, NITX, NITD, false>), grid, dim3(WD_THREADS), lds_bytes, st, table_dev, n);
+    }
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+// table_host: the n fully filled descriptors (all wgrad_deep-eligible, same stride, all with or all without a two-tensor gradient
+// prologue); table_dev: the same bytes in device memory (the kernel reads its descriptor from there)
+extern "C" int sisr_wgrad_deep_batch(const SisrWgradDesc* table_host, const SisrWgradDesc* table_dev, int32_t n, void* stream) {
+    if (!table_host || !table_dev || n <= 0 || n > 4096) return SISR_E_BADARG;
+    const int S = table_host[0].stride;
+    const bool two = operand_needs_x2(table_host[0].gpro_mode);
+    int total = 0, lds = 0;
+    for (int i = 0; i < n; ++i) {
+        const SisrWgradDesc* d = table_host + i;
+        const SisrWgradDeepPlan& p = d->deep;
+        if (!sisr_wgrad_deep_eligible(d) || d->stride != S || operand_needs_x2(d->gpro_mode) != two) return SISR_E_BADARG;
+        if (!d->x1 || !d->g1 || !d->slab || (two && !d->g2) || d->slab_stride < d->slab_elems) return SISR_E_BADARG;
+        if (d->pro_mode == SISR_PRO_AFFINE_ACT && (!d->pa || !d->pd)) return SISR_E_BADARG;
+        const int gp = d->gpro_mode;
+        if ((gp == SISR_PRO_BNBWD || gp == SISR_PRO_BNACT_BWD) && (!d->qa || !d->qb || !d->qd)) return SISR_E_BADARG;
+        if (gp == SISR_PRO_BNACT_BWD && (!d->qs || !d->qt)) return SISR_E_BADARG;
+        if (p.n_pb <= 0 || p.tiles_per_pb <= 0 || (p.n_pb - 1) * p.tiles_per_pb >= p.n_tiles) return SISR_E_BADARG;
+        if (S == 1 ? (p.NITX > 6 || p.NITD > 4) : (p.NITX > 10 || p.NITD > 3)) return SISR_E_BADARG;
+        if (p.batch_first_wg != total) return SISR_E_BADARG;       // the caller numbers the members' workgroups consecutively
+        total += p.n_cib * p.n_cob * p.n_pb;
+        lds = std::max(lds, p.lds_bytes);
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(total);
+    return S == 1 ? launch_wd_table<1, 6, 4>(table_dev, n, grid, lds, two, st) : launch_wd_table<2, 10, 3>(table_dev, n, grid, lds, two, st);
 }

@@ -10,6 +10,8 @@ materialisation is the final 16 x fc_in flatten.  The data gradient of the strid
 four output-parity classes (stride-1 convs with 1/2/2/4 taps) -- no zero-stuffed work.  The FC
 layers stream their 75-302 MB weight exactly once per pass.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -89,6 +91,8 @@ def run_backward(sv, grad_out, need_dx, sink=None, params=()):
     topo, P = sv.topo, sv.P
     grads = {}
     wg = E.WeightGradBatch()
+    pending = E.PendingSlabs()            # the layers' slab reductions wait for the flush: one launch instead of one per layer
+    wb = E.WgradDeepBatch()               # ... and so do the weight-gradient kernels of the 3x3 stack themselves (one launch per stride)
     grad_out = grad_out.contiguous()
     n = sv.x.shape[0]
     by_id = {id(p): p for p in params}
@@ -97,6 +101,8 @@ def run_backward(sv, grad_out, need_dx, sink=None, params=()):
 
     def flush(tag):
         """un-pack the weight gradients collected so far (one launch) and announce every new gradient to the sink"""
+        wb.run(pending)
+        pending.flush()
         for ref_id, (gw, gb) in wg.run().items():
             ref = next(r for r in refs if id(r) == ref_id)
             if gw is not None:
@@ -133,7 +139,8 @@ def run_backward(sv, grad_out, need_dx, sink=None, params=()):
         p = P[id(ref)]
         want_w, want_b = ref.weight.requires_grad, ref.bias is not None and ref.bias.requires_grad
         if want_w or want_b:
-            wg.add(p, E.conv_wgrad(p, x_op, dy_op), want_w, want_b)
+            red = wb.add(p, x_op, dy_op)
+            wg.add(p, red if red is not None else E.conv_wgrad(p, x_op, dy_op, defer=pending), want_w, want_b)
         if not need_dgrad:
             return None
         if bnb is None:
@@ -178,7 +185,6 @@ class DiscriminatorFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         grads, gx = run_backward(ctx.sv, grad_out, ctx.needs_input_grad[3], sink=ctx.sink, params=ctx.params)
-        ctx.sv = None
         return (None, None, None, gx) + tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
 
 

@@ -442,8 +442,9 @@ def prepare_weights(items, training, need_dgrad=True, cache=None):
                 if not deep_hit:
                     t.wdp_dgrad = p.wpk_dgrad.data_ptr()
         elif kinds[1]:
-            t.wbf_dgrad, t.bf_d_CoutPad, t.bf_d_CK = p.wpk_dgrad.data_ptr(), d.plan.CoutPad, d.plan.CK
-            t.bf_d_lanes = int(p.lanes[1] and off_d is not None)
+            if off_d is not None:                                     # (need_dgrad=False: no data-gradient image is packed)
+                t.wbf_dgrad, t.bf_d_CoutPad, t.bf_d_CK = p.wpk_dgrad.data_ptr(), d.plan.CoutPad, d.plan.CK
+                t.bf_d_lanes = int(p.lanes[1])
         else:
             t.wpk_dgrad = None if isinstance(p.wpk_dgrad, list) else _ptr(p.wpk_dgrad)
             t.d_ldsimg = p.ldsimg[1] if (off_d is not None and not isinstance(off_d, list)) else 0
@@ -808,11 +809,18 @@ class PendingSlabs:
         return self.jobs.pop(0) if self.jobs else None
 
     def flush(self):
-        lib = L.lib()
-        while self.jobs:
-            slab, red, n_slabs, stride, lead = self.jobs.pop(0)
-            L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), red.data_ptr(), n_slabs, stride, lead, _stream()),
-                    'sisr_slab_reduce_f32')
+        """whatever is left, in ONE launch per eight jobs (sisr_slab_reduce_multi: the jobs travel in the kernel arguments)"""
+        if not self.jobs:
+            return
+        jobs, self.jobs = self.jobs, []
+        n = len(jobs)
+        slabs = (C.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
+        outs = (C.c_void_p * n)(*[j[1].data_ptr() for j in jobs])
+        counts = (C.c_int32 * n)(*[j[2] for j in jobs])
+        elems = (C.c_int64 * n)(*[j[3] for j in jobs])
+        leads = (C.c_int64 * n)(*[j[4] for j in jobs])
+        L.check(L.lib().sisr_slab_reduce_multi(C.addressof(slabs), C.addressof(outs), C.addressof(counts), C.addressof(elems),
+                                               C.addressof(leads), n, _stream()), 'sisr_slab_reduce_multi')
 
 
 def conv_wgrad(prep, x_op, dy_op, defer=None):
@@ -860,6 +868,74 @@ def conv_wgrad(prep, x_op, dy_op, defer=None):
     L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), red.data_ptr(), n_slabs, stride, lead, _stream()),
             'sisr_slab_reduce_f32')
     return red
+
+
+class WgradDeepBatch:
+    """Weight gradients of the layers that run on wgrad_deep.hip, collected during a backward pass and launched TOGETHER (one launch
+    per stride: grid z = layer).  Nothing consumes a weight gradient before the optimizer step, so a schedule may hold them back;
+    at 96 x 96 a layer alone spreads 4 tiles per workgroup over the chip and pays ~15 us of prologue and slab stores for ~6 us of
+    work, while a batch plans every member for its SHARE of the chip: 3-4 times the tiles per workgroup behind the same fixed costs,
+    a third of the slabs.  add() returns the buffer the reduced gradient WILL be in -- valid after run(pending) and pending.flush()."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, prep, x_op, dy_op):
+        """-> reduced-gradient buffer, or None when the layer does not qualify (the caller then runs conv_wgrad as usual)"""
+        if not prep.kinds[2] or os.environ.get('SISR_WGRAD_BATCH', '1') == '0':
+            return None
+        g = _copy_struct(prep.plans[2])
+        if not g.deep.enabled:
+            return None
+        x_op.fill(g)
+        dy_op.fill(g, g=True)
+        lib = L.lib()
+        # (the persistent trunk kernel and the last conv's kernel come first in sisr_conv2d_wgrad_bf16's dispatch: theirs stay theirs)
+        if lib.sisr_wgrad_trunk_eligible(C.byref(g)) or lib.sisr_wgrad_toimage_eligible(C.byref(g)) or not lib.sisr_wgrad_deep_eligible(C.byref(g)):
+            return None
+        red = torch.empty((g.slab_stride,), dtype=torch.float32, device=x_op.x1.device)
+        self.items.append((prep, g, x_op, dy_op, red))              # (the operands' tensors stay alive until run())
+        return red
+
+    def run(self, pending):
+        """launch what was collected; the slab sums are left with `pending` (PendingSlabs: the caller flushes it)"""
+        if not self.items:
+            return
+        lib = L.lib()
+        items, self.items = self.items, []
+        groups = {}
+        for it in items:
+            g = it[1]
+            groups.setdefault((g.stride, g.gpro_mode in (L.PRO_BNBWD, L.PRO_BNACT_BWD, L.PRO_ACT_BWD)), []).append(it)
+        for group in groups.values():
+            work = [float(g.N) * g.Ho * g.Wo * g.Cin * g.Cout for _, g, _, _, _ in group]
+            tot = sum(work)
+            table = (L.WgradDesc * len(group))()
+            keep, first_wg = [], 0
+            for i, (prep, g, x_op, dy_op, red) in enumerate(group):
+                if len(group) > 1:
+                    blocks = (g.Cin // 64) * (g.Cout // 64)
+                    share = max(blocks, int(round(256.0 * work[i] / tot)))
+                    cache, key = prep.ref.geom._plans, ('wgrad_deep_share', g.N, g.H, g.W, share, os.environ.get('SISR_SLAB_BF16', '1'))
+                    if key not in cache:
+                        t = _copy_struct(g)
+                        L.check(lib.sisr_wgrad_deep_plan(C.byref(t), share), 'sisr_wgrad_deep_plan(share)')
+                        cache[key] = _copy_struct(t.deep)
+                    g.deep = cache[key]
+                n_slabs = g.deep.n_pb
+                g.deep.batch_first_wg = first_wg
+                first_wg += g.deep.n_cib * g.deep.n_cob * n_slabs
+                slab = torch.empty((n_slabs, g.slab_stride), dtype=torch.float32, device=red.device)
+                g.slab = slab.data_ptr()
+                g.bias_slab = slab.data_ptr() + 4 * g.slab_elems
+                table[i] = g
+                lead = int(lib.sisr_wgrad_bf16_slab_lead(C.byref(g)))
+                pending.jobs.append((slab, red, n_slabs, g.slab_stride, lead))
+                keep.append(slab)
+            dev = _table_to_device(table, group[0][4].device)
+            L.check(lib.sisr_wgrad_deep_batch(table, dev.data_ptr(), len(group), _stream()), 'sisr_wgrad_deep_batch')
+            KERNEL_COUNTS['wgrad_deep'] = KERNEL_COUNTS.get('wgrad_deep', 0) + len(group)
+            KERNEL_COUNTS['wgrad_deep_batch'] = KERNEL_COUNTS.get('wgrad_deep_batch', 0) + 1
 
 
 class WeightGradBatch:

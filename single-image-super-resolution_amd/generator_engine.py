@@ -170,12 +170,18 @@ def run_backward(sv, grad_out, need_dx, sink=None, params=()):
     grads = {}
     wg = E.WeightGradBatch()
     pending = E.PendingSlabs()            # slab sums of the weight gradients, carried by the next BatchNorm-backward finish
+    # trunk sizes the persistent kernels do not take (24 x 24 maps of a x4 / x8 generator): the weight gradients of the 3x3 layers are
+    # collected and launched together at the flush (engine.WgradDeepBatch); their slab sums wait in a list of their own -- a
+    # BatchNorm-backward finish must not pick up a slab set whose kernel has not run yet
+    wb, pending_b = E.WgradDeepBatch(), E.PendingSlabs()
     by_id = {id(p): p for p in params}
     announced = set()
     all_refs = [r for r in topo.conv_refs() if r is not None]
 
     def flush(tag):
         """un-pack the weight gradients collected so far (one launch) and announce every new gradient to the sink"""
+        wb.run(pending_b)
+        pending_b.flush()
         pending.flush()
         for ref_id, (gw, gb) in wg.run().items():
             ref = next(r for r in all_refs if id(r) == ref_id)
@@ -196,7 +202,8 @@ def run_backward(sv, grad_out, need_dx, sink=None, params=()):
         p = P[id(ref)]
         want_w, want_b = ref.weight.requires_grad, ref.bias is not None and ref.bias.requires_grad
         if want_w or want_b:
-            wg.add(p, E.conv_wgrad(p, x_op, dy_op, defer=pending), want_w, want_b)
+            red = wb.add(p, x_op, dy_op)
+            wg.add(p, red if red is not None else E.conv_wgrad(p, x_op, dy_op, defer=pending), want_w, want_b)
         if not need_dgrad:
             return None
         if bnb is None:

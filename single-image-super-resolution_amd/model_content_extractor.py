@@ -87,7 +87,7 @@ def vgg_4conv_1maxPool(pretrained=True):
         path = os.environ.get('SISR_VGG19_WEIGHTS')
         try:
             if path:
-                sd = torch.load(path, map_location='cpu')
+                sd = torch.load(path, map_location='cpu', weights_only=True)      # a state_dict: tensors only, no pickled code
                 sd = {k[len('features.'):]: v for k, v in sd.items() if k.startswith('features.')} or sd
                 sd = {k: v for k, v in sd.items() if int(k.split('.')[0]) < 9}
             else:
@@ -139,7 +139,7 @@ class MaskedVGG(nn.Module):
         path = os.environ.get('SISR_VGG19_WEIGHTS')
         try:
             if path:
-                sd = torch.load(path, map_location='cpu')
+                sd = torch.load(path, map_location='cpu', weights_only=True)      # a state_dict: tensors only, no pickled code
                 sd = {k[len('features.'):]: v for k, v in sd.items() if k.startswith('features.')} or sd
                 sd = {k: v for k, v in sd.items() if int(k.split('.')[0]) < n}
             else:

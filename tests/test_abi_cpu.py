@@ -274,3 +274,5 @@ def test_resize_coefficient_tables_match_the_oracle():
         ks_o, b_o, kk_o = oo.pil_bilinear_coeffs(n_in, n_out)
         assert ks == ks_o and np.array_equal(bounds, b_o) and np.array_equal(kk, kk_o), (n_in, n_out)
     assert lib.sisr_resize_coeffs(0, 4, None, None) < 0
+    # more than 64 taps per output index (a down-scale above ~31x): refused by the size query as well as by the fill
+    assert lib.sisr_resize_coeffs(4096, 64, None, None) < 0 and lib.sisr_resize_coeffs(1984, 64, None, None) == 63

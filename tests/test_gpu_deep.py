@@ -355,3 +355,28 @@ def test_full_size_layers_weight_gradient(E, L, case):
     assert maxrel(gw, gw_ref) < TOL
     l1 = g.abs().sum(dim=(0, 2, 3))
     assert float(((gb.double().cpu() - g.sum(dim=(0, 2, 3))).abs() / l1.clamp_min(1e-30)).max()) < 2e-3
+
+
+@pytest.mark.parametrize('stride', [1, 2])
+def test_weight_gradients_of_several_layers_in_one_launch(E, L, stride):
+    """WgradDeepBatch: layers of one stride collected and launched together (grid z = layer), every member planned for its share of the
+    chip -- same results as the layer alone within the slab rounding, and the reference holds for every member"""
+    cases = {1: [(16, 64, 128, 1, 48, 48), (16, 128, 256, 1, 24, 24), (16, 256, 512, 1, 12, 12), (3, 64, 64, 1, 13, 11)],
+             2: [(16, 64, 64, 2, 96, 96), (16, 128, 128, 2, 48, 48), (16, 256, 256, 2, 24, 24), (16, 512, 512, 2, 12, 12)]}[stride]
+    members = [_wgrad_case(E, L, c, 'affine_act', 'bnact_bwd', seed=7 * i) for i, c in enumerate(cases)]
+    alone = [_run_wgrad(E, p, ref, x_op, g_op) for p, ref, x_op, g_op, _, _ in members]
+    wb, pending, wg = E.WgradDeepBatch(), E.PendingSlabs(), E.WeightGradBatch()
+    before = E.KERNEL_COUNTS.get('wgrad_deep_batch', 0)
+    for p, ref, x_op, g_op, _, _ in members:
+        red = wb.add(p, x_op, g_op)
+        assert red is not None
+        wg.add(p, red)
+    wb.run(pending)
+    assert E.KERNEL_COUNTS.get('wgrad_deep_batch', 0) == before + 1 and len(pending.jobs) == len(members)
+    pending.flush()
+    res = wg.run()
+    for (p, ref, x_op, g_op, gw_ref, g), (gw1, gb1) in zip(members, alone):
+        gw, gb = res[id(ref)]
+        assert maxrel(gw, gw_ref) < TOL and maxrel(gw, gw1) < TOL
+        l1 = g.abs().sum(dim=(0, 2, 3))
+        assert float(((gb.double().cpu() - g.sum(dim=(0, 2, 3))).abs() / l1.clamp_min(1e-30)).max()) < 2e-3

@@ -1,6 +1,8 @@
 """GPU: kernel-level parity of the C ABI entry points against torch-CPU primitives (the same
 primitives the oracle restates).  Tolerance 1e-4 relative (fp32 MFMA is an exact fmaf chain; only
 summation order differs)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -413,6 +415,31 @@ def test_bn_backward_finish_carries_a_slab_reduction(E, L):
         pend.jobs.append((slab, red2, n_slabs, stride, lead))
         E.bn_backward(x, x, consts, gamma, slope=slope, part=part, slabs=pend)
         assert torch.equal(red2, red)
+
+
+def test_several_slab_reductions_in_one_launch(E, L):
+    """sisr_slab_reduce_multi (PendingSlabs.flush): up to eight jobs per launch, each bit-identical to sisr_slab_reduce_f32 on the same
+    slabs -- many slabs (16 columns x 16 splits per workgroup) and few (one column per thread) mixed in one launch, fp32 and
+    bf16-lead rows, eleven jobs = two launches"""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(9)
+    st = torch.cuda.current_stream().cuda_stream
+    shapes = [(231, 36928, 36864), (1, 4096 + 64, 4096), (3, 1028, 0), (16, 260, 256), (17, 260, 256), (64, 36928, 36864), (2, 64, 64),
+              (5, 2304 + 64, 0), (12, 148, 128), (40, 16 * 4 * 5 + 4, 0), (4, 589824 + 512, 589824)]
+    pend, want = E.PendingSlabs(), []
+    for n_slabs, stride, lead in shapes:
+        slab = (torch.rand(n_slabs, stride, generator=g) - 0.5).cuda()
+        if lead:
+            slab.view(torch.bfloat16)[:, :lead] = (torch.rand(n_slabs, lead, generator=g) - 0.5).bfloat16().cuda()
+        ref = torch.empty(stride, device='cuda')
+        L.check(lib.sisr_slab_reduce_f32(slab.data_ptr(), ref.data_ptr(), n_slabs, stride, lead, st), 'slab_reduce')
+        red = torch.full((stride,), float('nan'), device='cuda')
+        pend.jobs.append((slab, red, n_slabs, stride, lead))
+        want.append((red, ref))
+    pend.flush()
+    assert pend.jobs == []
+    for i, (red, ref) in enumerate(want):
+        assert torch.equal(red, ref), shapes[i]
 
 
 def _merged_stats(sp, cp):
@@ -1121,6 +1148,54 @@ def test_thin_kernel_first_conv_weight_gradient(E, L, shape, act, monkeypatch):
         gw, gb = wg.run()[id(ref)]
         assert maxrel(gw, wr.grad) < 2e-3 and maxrel(gb, br.grad) < 2e-3
         monkeypatch.setenv('SISR_THIN', '1')
+        assert torch.equal(E.conv_wgrad(p, x_op, dy_op), red['1'])
+    finally:
+        E.set_precision('fp32')
+
+
+@pytest.mark.parametrize('act', [True, False])
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 24, 64), (3, 24, 64, 3), (16, 96, 96), (2, 192, 192)])
+def test_thin_kernel_discriminator_first_conv_weight_gradient(E, L, shape, act, monkeypatch):
+    """wgrad_thin.hip, KS = 3 -- weight / bias gradient of the discriminator's first conv (model_discriminator.py:36: 3x3, 3 -> 64 over
+    the NCHW fp32 image; the gradient arrives through the LeakyReLU) -- against the generic exact-fp32 kernel the same descriptor runs
+    on with SISR_THIN3=0 and against autograd"""
+    n, h, w = _walk(shape, monkeypatch)
+    monkeypatch.setenv('SISR_STORAGE', 'bf16')
+    bf = lambda t: t.bfloat16().float()
+    x = _rand((n, 3, h, w), 321)
+    wt = _rand((64, 3, 3, 3), 322, (1.0 / 27) ** 0.5 * 1.7)
+    b = _rand((64,), 323, 0.1)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pre_ref = F.conv2d(bf(x), wr, br, padding=1)               # (the kernel multiplies bf16-rounded image values)
+    pre = bf(pre_ref.detach())
+    g = bf(_rand((n, 64, h, w), 324))
+    gpre = bf(torch.where(pre > 0, g, 0.2 * g)) if act else g
+    pre_ref.backward(gpre)
+    E.set_precision('bf16')
+    try:
+        ref = FakeConv(wt.cuda(), b.cuda(), E.ConvGeom(3, 64, 3, 1, 1))
+        p = E.prepare_weights([(ref, n, h, w)], training=True, need_dgrad=False)[0][0]
+        x_op = E.Operand.plain(x.cuda(), dims=(n, h, w, 3), mode=L.X_NCHW)
+        gd, pd_ = nhwc(g).cuda().bfloat16(), nhwc(pre).cuda().bfloat16()
+        dy_op = E.Operand(gd, (n, h, w, 64), pro=L.PRO_ACT_BWD, x2=pd_, slope=0.2) if act else E.Operand.plain(gd)
+        red = {}
+        for sw in ('1', '0'):
+            monkeypatch.setenv('SISR_THIN3', sw)
+            gdesc = E._copy_struct(p.plans[2])
+            x_op.fill(gdesc)
+            dy_op.fill(gdesc, g=True)
+            assert bool(L.lib().sisr_wgrad_thin_eligible(C.byref(gdesc))) == (sw == '1')
+            red[sw] = E.conv_wgrad(p, x_op, dy_op)
+        assert red['1'].shape == red['0'].shape == (3 * 12 * 64 + 64,)
+        # packed layout [ky][kx * 3 + ci, padded 9 -> 12][co] + bias row; this kernel writes zeros into the padding rows
+        body = lambda r: torch.cat([r[:3 * 12 * 64].view(3, 12, 64)[:, :9].reshape(-1), r[3 * 12 * 64:]])
+        assert maxrel(body(red['1']), body(red['0'])) < 8e-3     # (fp32 image values / unrounded act' there)
+        assert float(red['1'][:3 * 12 * 64].view(3, 12, 64)[:, 9:].abs().max()) == 0.0
+        wg = E.WeightGradBatch()
+        wg.add(p, red['1'])
+        gw, gb = wg.run()[id(ref)]
+        assert maxrel(gw, wr.grad) < 2e-3 and maxrel(gb, br.grad) < 2e-3
+        monkeypatch.setenv('SISR_THIN3', '1')
         assert torch.equal(E.conv_wgrad(p, x_op, dy_op), red['1'])
     finally:
         E.set_precision('fp32')
