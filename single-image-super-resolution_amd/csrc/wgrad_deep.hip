@@ -154,7 +154,11 @@ __device__ __forceinline__ void wgrad_deep_body(const SisrWgradDesc& d, unsigned
         const unsigned cx = (unsigned)(cib * 64 + oct * 8) * 2u, cg = (unsigned)(cob * 64 + oct * 8) * 2u;
         const float xslope = d.pro_slope_p ? d.pro_slope_p[0] : d.pro_slope;
         const float gslope = d.gpro_slope_p ? d.gpro_slope_p[0] : d.gpro_slope;
+#ifdef WD_DBG_NOXFORM                   // developer build: every prologue is a plain copy -- what the transforms' vector work costs
+        const int xpro = SISR_PRO_NONE, gpro = TWO ? SISR_PRO_ACT_BWD : SISR_PRO_NONE;
+#else
         const int xpro = d.pro_mode, gpro = d.gpro_mode;
+#endif
         f32x8 bsum = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
         struct Set {
@@ -286,7 +290,11 @@ __device__ __forceinline__ void wgrad_deep_body(const SisrWgradDesc& d, unsigned
     WD_BARRIER();                                                  // tile 0 is in buffer 0
     for (int i = 0; i < ntile; ++i) {
         const unsigned char* buf = lds + (i & 1) * BUF;
+#ifdef WD_DBG_NOK                       // developer build (tools/wd_dbg.sh): the consumers only keep the barriers -- what the producers cost alone
+        const int nks = 0;
+#else
         const int nks = tile_geom(t_begin + i).npos >> 4;
+#endif
         // K steps of 16 positions; taps in two groups (5 + 4): the fragments of one group are requested while the MFMAs of the
         // other run (pinned order -- left alone the scheduler sinks every read to just before its use)
         bf16x8 bcur, bnext, fa[5], fb[4];

@@ -890,9 +890,15 @@ class WgradDeepBatch:
         x_op.fill(g)
         dy_op.fill(g, g=True)
         lib = L.lib()
-        # (the persistent trunk kernel and the last conv's kernel come first in sisr_conv2d_wgrad_bf16's dispatch: theirs stay theirs)
-        if lib.sisr_wgrad_trunk_eligible(C.byref(g)) or lib.sisr_wgrad_toimage_eligible(C.byref(g)) or not lib.sisr_wgrad_deep_eligible(C.byref(g)):
+        # (the last conv's kernel comes first in sisr_conv2d_wgrad_bf16's dispatch and stays; so does the persistent trunk kernel
+        # where its 8 x 16 tiles fill the chip -- at LR 48 they are 288 for 256 CUs: 144 workgroups of two, and the batch measured
+        # 366 us for the 33 trunk layers against 33 x 16.5 us)
+        if lib.sisr_wgrad_toimage_eligible(C.byref(g)) or not lib.sisr_wgrad_deep_eligible(C.byref(g)):
             return None
+        if lib.sisr_wgrad_trunk_eligible(C.byref(g)):
+            if g.N * g.H * g.W >= 384 * 128 or os.environ.get('SISR_WGRAD_BATCH_TRUNK', '1') == '0':
+                return None
+            # (sisr_wgrad_bf16_slab_lead answers for the trunk kernel then: the same SISR_SLAB_BF16 rule as wgrad_deep.hip's)
         red = torch.empty((g.slab_stride,), dtype=torch.float32, device=x_op.x1.device)
         self.items.append((prep, g, x_op, dy_op, red))              # (the operands' tensors stay alive until run())
         return red
