@@ -896,7 +896,7 @@ class WgradDeepBatch:
         if lib.sisr_wgrad_toimage_eligible(C.byref(g)) or not lib.sisr_wgrad_deep_eligible(C.byref(g)):
             return None
         if lib.sisr_wgrad_trunk_eligible(C.byref(g)):
-            if g.N * g.H * g.W >= 384 * 128 or os.environ.get('SISR_WGRAD_BATCH_TRUNK', '1') == '0':
+            if g.N * g.H * g.W >= int(os.environ.get('SISR_WGRAD_BATCH_TRUNK_PIXELS', 384 * 128)) or os.environ.get('SISR_WGRAD_BATCH_TRUNK', '1') == '0':
                 return None
             # (sisr_wgrad_bf16_slab_lead answers for the trunk kernel then: the same SISR_SLAB_BF16 rule as wgrad_deep.hip's)
         red = torch.empty((g.slab_stride,), dtype=torch.float32, device=x_op.x1.device)
