@@ -37,6 +37,9 @@ class Saved:
     pass
 
 
+KEEP_SAVED = None       # test hook: a list -> run_forward appends its saved state (raw conv outputs, BatchNorm constants: the activation masks)
+
+
 def run_forward(topo, x, training):
     E.require_gpu_tensor(x, 'discriminator input')
     x = x.contiguous()
@@ -75,6 +78,8 @@ def run_forward(topo, x, training):
         sv.out = E.fc_forward(sv.h1, topo.fc2.weight, topo.fc2.bias, in_slope=LEAKY, sigmoid=True)
     if training and topo.blocks:
         torch._foreach_add_([bn.num_batches_tracked for _, bn in topo.blocks], 1)
+    if KEEP_SAVED is not None:
+        KEEP_SAVED.append(sv)
     return sv.out, sv
 
 

@@ -154,7 +154,12 @@ def run_forward(topo, x, training):
     sv.out = out
     if training:
         torch._foreach_add_([m.num_batches_tracked for m in topo.bn_modules()], 1)
+    if KEEP_SAVED is not None:
+        KEEP_SAVED.append(sv)
     return out, sv
+
+
+KEEP_SAVED = None       # test hook: a list -> run_forward appends its saved state (pre-activations, BatchNorm constants: the PReLU masks)
 
 
 def run_backward(sv, grad_out, need_dx, sink=None, params=()):

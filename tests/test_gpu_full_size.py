@@ -286,3 +286,84 @@ def test_full_size_discriminator_matches_the_oracle():
     out = _flip_aware_compare(net, cfg, state, x, r,
                               strict_keys=('fc.', 'conv.2.2.', 'conv.2.3.', 'conv.2.4.', 'conv.2.5.', 'conv.2.6.'))
     assert tuple(out.shape) == (16, 1)
+
+
+def test_full_size_discriminator_gradients_with_the_hip_paths_masks_forced():
+    """The flip-INSENSITIVE full-size check: the same B16 / 96^2 discriminator case, but the fp32 oracle is made to take the
+    HIP path's own LeakyReLU masks (oracle.ops.ACT_MASKS: the sign of every pre-activation as the HIP forward computed it, read from the
+    state its backward keeps) -- both sides then differentiate the same piecewise-linear function, so EVERY gradient tensor, the three
+    96^2 / 48^2 layers and the input gradient included, is held to the plain 1e-3 instead of the flip-sized bounds.  A kernel that reads
+    a wrong halo column on an edge tile only at multi-tile sizes has nowhere to hide here."""
+    from oracle import init as oinit
+    E, md, de = pkg('engine'), pkg('model_discriminator'), pkg('discriminator_engine')
+    E.set_precision('fp32')
+    feats, strides = [64, 64, 128, 128, 256, 256, 512, 512], [1, 2, 1, 2, 1, 2, 1, 2]
+    torch.manual_seed(0)
+    net = md.Discriminator((3, 96, 96), feats, strides).cuda().train()
+    state = oinit.synth_state({k: tuple(v.shape) for k, v in net.state_dict().items()}, 6)
+    g = torch.Generator().manual_seed(22)
+    x = torch.rand(16, 3, 96, 96, generator=g) * 2 - 1
+    r = torch.rand(16, 1, generator=g) * 2 - 1
+    cfg = {'kind': 'discriminator', 'list_stride': strides}
+    nchw_ = lambda t: t.permute(0, 3, 1, 2).contiguous().cpu()
+
+    def masks_of(sv):
+        m = [nchw_(sv.c0.float() > 0)]
+        for c, k in zip(sv.cs, sv.ks):
+            m.append(nchw_(k[0].double() * c.double() + k[1].double() > 0))          # BatchNorm output = scale * conv + shift
+        return m + [(sv.h1 > 0).cpu()]
+    flips = _forced_mask_compare(de, net, cfg, state, x, r, masks_of)
+    assert len(flips) == 9
+
+
+def _forced_mask_compare(engine_mod, net, cfg, state, x, r, masks_of):
+    """HIP forward+backward, then the fp32 oracle with the HIP path's activation masks (masks_of(saved state) in the oracle's forward
+    order) forced: output and EVERY gradient tensor at the plain 1e-3.  -> number of mask elements the oracle alone decides otherwise"""
+    from oracle import ops as oops
+    from helpers import analytically_zero
+    engine_mod.KEEP_SAVED = []
+    try:
+        out, gx, got, sd = _gpu_fwd_bwd(net, state, x, r)
+        sv = engine_mod.KEEP_SAVED[-1]
+    finally:
+        engine_mod.KEEP_SAVED = None
+    masks = masks_of(sv)
+    own, orig = [], oops._positive
+    oops._positive = lambda t: (own.append((t > 0).detach()), own[-1])[1]
+    try:
+        oracle_fwd_bwd(cfg, state, x, r)
+    finally:
+        oops._positive = orig
+    assert len(own) == len(masks)
+    flips = [int((a != b).sum()) for a, b in zip(own, masks)]
+    oops.ACT_MASKS = list(masks)
+    try:
+        o_out, o_gx, o_grads, _ = oracle_fwd_bwd(cfg, state, x, r)
+        assert oops.ACT_MASKS == []
+    finally:
+        oops.ACT_MASKS = None
+    assert rel_err(out, o_out) < TOL
+    got['grad_x'], o_grads['grad_x'] = gx, o_gx
+    bad = [(k, rel_err(got[k], v)) for k, v in o_grads.items() if not analytically_zero(k, o_grads) and not rel_err(got[k], v) < TOL]
+    assert bad == [], (bad, flips)
+    return flips
+
+
+@pytest.mark.parametrize('lr,init', [(48, 'default'), (96, 'synthetic')])
+def test_full_size_generator_gradients_with_the_hip_paths_masks_forced(lr, init):
+    """the flip-insensitive check for the generator: Generator(16, 64, 256, [2], use_sn=True), B16, LR 48 / LR 96, the reference's own
+    PReLU slopes (0.25), fp32 parity build; the oracle takes the 18 PReLU masks of the HIP forward (first conv, 16 blocks, upscale), and
+    every one of the ~150 gradient tensors and the input gradient is held to 1e-3 -- where test_full_size_generator_with_the_
+    references_activations has to allow flip-sized 5e-2 / 5e-3"""
+    E, ge = pkg('engine'), pkg('generator_engine')
+    E.set_precision('fp32')
+    net, cfg, state, x, r = _generator_case(lr, init)
+    nchw_ = lambda t: t.permute(0, 3, 1, 2).contiguous().cpu()
+
+    def masks_of(sv):
+        m = [nchw_(sv.t0_pre.float() > 0)]
+        for rec in sv.blocks:
+            m.append(nchw_(rec.k1[0].double() * rec.c1.double() + rec.k1[1].double() > 0))
+        return m + [nchw_(pre.float() > 0) for pre in sv.stage_pre]
+    flips = _forced_mask_compare(ge, net, cfg, state, x, r, masks_of)
+    assert len(flips) == 18
