@@ -270,7 +270,7 @@ int sisr_wgrad_deep_plan(SisrWgradDesc *d, int32_t target_wg);
 /* a fully filled descriptor (operands, modes, storage flags) will run on wgrad_deep.hip */
 int sisr_wgrad_deep_eligible(const SisrWgradDesc *d);
 /* Several wgrad_deep.hip layers in one launch (a flat grid; deep.batch_first_wg, filled by the caller = the workgroups of the members
- * in front, n_cib * n_cob * n_pb each, every member starting on a multiple of 8): table_host = n fully filled, eligible descriptors of one stride, all
+ * in front, n_cib * n_cob * n_pb each): table_host = n fully filled, eligible descriptors of one stride, all
  * with or all without a two-tensor gradient prologue; table_dev = the same bytes in device memory.  Plan each member with its share
  * of the chip as target_wg (sisr_wgrad_deep_plan): the batch then walks 3-4 times as many tiles per workgroup behind the same fixed
  * costs and writes a third of the slabs.  Results per layer are those of sisr_conv2d_wgrad_bf16 on the same plan. */

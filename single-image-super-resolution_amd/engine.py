@@ -929,7 +929,6 @@ class WgradDeepBatch:
                         cache[key] = _copy_struct(t.deep)
                     g.deep = cache[key]
                 n_slabs = g.deep.n_pb
-                first_wg = (first_wg + 7) & ~7                              # (members start on a multiple of 8: XCD alignment)
                 g.deep.batch_first_wg = first_wg
                 first_wg += g.deep.n_cib * g.deep.n_cob * n_slabs
                 slab = torch.empty((n_slabs, g.slab_stride), dtype=torch.float32, device=red.device)
