@@ -672,6 +672,13 @@ extern "C" int sisr_conv2d_deep_plan(SisrConvDesc* d, int32_t target_wg, int32_t
     const int n_mtiles0 = p.tiles_x * p.tiles_q * classes;
     p.BN = (d->Cout % 128 == 0) ? 128 : 64;
     if (p.BN == 128 && prefer_bn != 128 && (prefer_bn == 64 || n_mtiles0 >= 128)) p.BN = 64;
+    // a 128-cout grid whose LAST round is less than half full (one workgroup per CU: 77 tiles x 4 cout tiles = 308 workgroups on 256 CUs
+    // run as two full-length rounds) takes 64-cout tiles whatever the prologue: two workgroups per CU start the tail as slots free up
+    // (measured at 24 x 24, B16: 512 -> 512 forward 114 -> 88 us, data gradient 153 -> 127 us; 256 -> 512 forward 63 -> 49 us)
+    if (p.BN == 128) {
+        const int base128 = n_mtiles0 * (d->Cout / 128), rem = base128 % 256;
+        if (base128 > 256 && base128 < 768 && rem > 0 && rem <= 128) p.BN = 64;
+    }
     if (const char* e = getenv("SISR_DEEP_BN")) { const int v = atoi(e); if (v == 64 || (v == 128 && d->Cout % 128 == 0)) p.BN = v; }   // A/B knob
     p.n_ntiles = d->Cout / p.BN;
     const int pad_bot = std::max(0, (d->Ho - 1) * S + d->KH - 1 - d->pad_y - (d->H - 1));
