@@ -275,6 +275,15 @@ int sisr_wgrad_deep_eligible(const SisrWgradDesc *d);
  * of the chip as target_wg (sisr_wgrad_deep_plan): the batch then walks 3-4 times as many tiles per workgroup behind the same fixed
  * costs and writes a third of the slabs.  Results per layer are those of sisr_conv2d_wgrad_bf16 on the same plan. */
 int sisr_wgrad_deep_batch(const SisrWgradDesc *table_host, const SisrWgradDesc *table_dev, int32_t n, void *stream);
+/* The same idea for the persistent trunk kernel (wgrad_trunk.hip: 3x3, 64 -> 64, bf16 NHWC, H % 8 == 0, W % 16 == 0): n fully filled
+ * descriptors that sisr_wgrad_trunk_eligible accepts, Cout = 64, ONE gradient-prologue kind (BNBWD or BNACT_BWD); wgs_per_layer
+ * workgroups -- and slabs: rows of each descriptor's `slab` -- serve every layer, grid = n * wgs_per_layer (choose 256 / n: each
+ * workgroup then walks its share of ONE layer's tiles back to back).  The kernel reads its own view of the descriptors:
+ * sisr_wgrad_trunk_batch_args fills n * sisr_wgrad_trunk_batch_arg_bytes() bytes of HOST memory, the caller copies them to the device
+ * and passes that copy as args_dev.  Per-tile arithmetic is that of sisr_conv2d_wgrad_bf16; only the partition into slabs differs. */
+int sisr_wgrad_trunk_batch_arg_bytes(void);
+int sisr_wgrad_trunk_batch_args(const SisrWgradDesc *descs, int32_t n, void *args_host);
+int sisr_wgrad_trunk_batch(const SisrWgradDesc *descs, const void *args_dev, int32_t n, int32_t wgs_per_layer, void *stream);
 int sisr_conv2d_wgrad_bf16(const SisrWgradDesc *d, void *stream);
 /* The trunk geometry with bf16 NHWC operands (x prologue NONE / ACT / AFFINE_ACT, gradient prologue BNBWD /
  * BNACT_BWD) runs on the persistent kernel of wgrad_trunk.hip behind sisr_conv2d_wgrad_bf16: one slab per workgroup,

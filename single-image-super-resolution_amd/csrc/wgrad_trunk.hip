@@ -24,6 +24,7 @@
 #include "sisr_bf16_stage.h"
 
 #include <algorithm>
+#include <cstring>
 #include <type_traits>
 #include <cstdlib>
 
@@ -97,9 +98,10 @@ __device__ __forceinline__ void wt_commit_x(const u32x4 (&sx)[WT_XITEMS], unsign
     }
 }
 
+// wg_index / wg_count: this workgroup's place among the workgroups that serve `a` (the grid of a launch of one layer; a
+// contiguous range of the grid of a batch of layers, wgrad_trunk_table_kernel)
 template <int GPRO>
-__global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunkArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+__device__ __forceinline__ void wgrad_trunk_body(const WTrunkArgs& a, const int wg_index, const int wg_count, unsigned char* lds) {
     // [2 buffers][x halo image | dy image], then the x prologue constants
     float* kst = reinterpret_cast<float*>(lds + 2 * (WT_XBYTES + WT_DBYTES));      // xa, xd: [2][64]
 
@@ -109,8 +111,8 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
     const int l31 = lane & 31;
     const int h = wave & 1, gq = (wave >> 1) & 1;             // consumer: output-channel half, input-channel chunk
     const unsigned xbytes = (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * 128u;
-    const int cg = blockIdx.x & ((1 << a.glog) - 1);                    // cout group (shuffle phase) of this workgroup
-    const int t_first = blockIdx.x >> a.glog, t_step = gridDim.x >> a.glog;
+    const int cg = wg_index & ((1 << a.glog) - 1);                      // cout group (shuffle phase) of this workgroup
+    const int t_first = wg_index >> a.glog, t_step = wg_count >> a.glog;
     auto tile_coords = [&](int T, int& n, int& ty, int& tx) {
         n = fdiv(T, a.m_per_img);
         const int rem = T - n * a.per_img;
@@ -353,6 +355,24 @@ __global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunk
     WTT(63);
 }
 
+template <int GPRO>
+__global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_kernel(const WTrunkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    wgrad_trunk_body<GPRO>(a, blockIdx.x, gridDim.x, lds);
+}
+
+// Several layers of one gradient-prologue kind in ONE launch: workgroups [z * wpl, (z + 1) * wpl) serve table[z].  The generator's 33
+// trunk layers alone are 33 launches of 231 workgroups x 5 tiles (1,152 tiles do not divide by 256 CUs: a tenth of the chip idles, and
+// every launch pays its pipeline fill and 231 slabs); as two batches (17 + 16 layers, 15 / 16 workgroups each) every workgroup walks
+// 72-77 tiles of ONE layer back to back and writes one slab: 15-16 slabs per layer instead of 231.
+template <int GPRO>
+__global__ void __launch_bounds__(WT_THREADS, 2) wgrad_trunk_table_kernel(const WTrunkArgs* __restrict__ table, const int wpl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int z = (int)blockIdx.x / wpl;
+    const WTrunkArgs a = table[z];
+    wgrad_trunk_body<GPRO>(a, (int)blockIdx.x - z * wpl, wpl, lds);
+}
+
 // ---- host ----------------------------------------------------------------------------------------------------------
 static int wtrunk_grid(const SisrWgradDesc* d) {
     const int total = d->N * (d->H / WT_TH) * (d->W / WT_TW);
@@ -423,12 +443,22 @@ static int launch_wtrunk(const WTrunkArgs& a, int grid, hipStream_t st) {
     return 0;
 }
 
+static WTrunkArgs wtrunk_args(const SisrWgradDesc* d);
+
 // called by sisr_conv2d_wgrad_bf16 for eligible descriptors
 int sisr_wgrad_trunk_launch(const SisrWgradDesc* d, hipStream_t st) {
     if (operand_needs_x2(d->gpro_mode) && !d->g2) return SISR_E_BADARG;
     if (d->pro_mode == SISR_PRO_AFFINE_ACT && (!d->pa || !d->pd)) return SISR_E_BADARG;
     if (d->gpro_mode != SISR_PRO_ACT_BWD && (!d->qa || !d->qb || !d->qd || (d->gpro_mode == SISR_PRO_BNACT_BWD && (!d->qs || !d->qt))))
         return SISR_E_BADARG;
+    const WTrunkArgs a = wtrunk_args(d);
+    const int grid = wtrunk_grid(d);
+    if (d->gpro_mode == SISR_PRO_ACT_BWD) return launch_wtrunk<SISR_PRO_ACT_BWD>(a, grid, st);
+    if (d->gpro_mode == SISR_PRO_BNBWD) return launch_wtrunk<SISR_PRO_BNBWD>(a, grid, st);
+    return launch_wtrunk<SISR_PRO_BNACT_BWD>(a, grid, st);
+}
+
+static WTrunkArgs wtrunk_args(const SisrWgradDesc* d) {
     WTrunkArgs a;
     a.x1 = d->x1; a.g1 = d->g1; a.g2 = d->g2;
     a.pa = d->pa; a.pd = d->pd; a.xslope_p = d->pro_slope_p; a.xslope = d->pro_slope;
@@ -441,8 +471,53 @@ int sisr_wgrad_trunk_launch(const SisrWgradDesc* d, hipStream_t st) {
     a.xpro = d->pro_mode;
     a.glog = d->Cout == 256 ? 2 : 0; a.cout_pad = d->Cout == 256 ? 256 : 64; a.gshuffle = d->g_mode == SISR_X_NHWC_UNSHUFFLE2 ? 1 : 0;
     a.slab_bf16 = wtrunk_slab_bf16() ? 1 : 0;
-    const int grid = wtrunk_grid(d);
-    if (d->gpro_mode == SISR_PRO_ACT_BWD) return launch_wtrunk<SISR_PRO_ACT_BWD>(a, grid, st);
-    if (d->gpro_mode == SISR_PRO_BNBWD) return launch_wtrunk<SISR_PRO_BNBWD>(a, grid, st);
-    return launch_wtrunk<SISR_PRO_BNACT_BWD>(a, grid, st);
+    return a;
+}
+
+// ---- a batch of trunk layers (Cout = 64, one gradient-prologue kind): see wgrad_trunk_table_kernel ---------------------------------
+extern "C" int sisr_wgrad_trunk_batch_arg_bytes(void) { return (int)sizeof(WTrunkArgs); }
+
+static int wtrunk_batch_check(const SisrWgradDesc* descs, int n) {
+    if (!descs || n <= 0 || n > 4096) return SISR_E_BADARG;
+    for (int i = 0; i < n; ++i) {
+        const SisrWgradDesc* d = descs + i;
+        if (!sisr_wgrad_trunk_eligible(d) || d->Cout != 64 || d->gpro_mode != descs[0].gpro_mode) return SISR_E_BADARG;
+        if (!d->x1 || !d->g1 || !d->g2 || !d->slab || d->slab_stride < d->slab_elems) return SISR_E_BADARG;
+        if (d->pro_mode == SISR_PRO_AFFINE_ACT && (!d->pa || !d->pd)) return SISR_E_BADARG;
+        if (!d->qa || !d->qb || !d->qd || (d->gpro_mode == SISR_PRO_BNACT_BWD && (!d->qs || !d->qt))) return SISR_E_BADARG;
+    }
+    return 0;
+}
+
+// fills args_host (n * sisr_wgrad_trunk_batch_arg_bytes() bytes) with the kernel's view of the n descriptors; the caller copies it to
+// device memory and passes that copy to sisr_wgrad_trunk_batch (the same staging route as every descriptor table of this library)
+extern "C" int sisr_wgrad_trunk_batch_args(const SisrWgradDesc* descs, int32_t n, void* args_host) {
+    if (!args_host) return SISR_E_BADARG;
+    if (int e = wtrunk_batch_check(descs, n)) return e;
+    for (int i = 0; i < n; ++i) {
+        const WTrunkArgs a = wtrunk_args(descs + i);
+        std::memcpy(static_cast<unsigned char*>(args_host) + (size_t)i * sizeof(WTrunkArgs), &a, sizeof(WTrunkArgs));
+    }
+    return 0;
+}
+
+// wgs_per_layer workgroups (= slabs, rows of each descriptor's `slab`) serve every layer; grid = n * wgs_per_layer
+extern "C" int sisr_wgrad_trunk_batch(const SisrWgradDesc* descs, const void* args_dev, int32_t n, int32_t wgs_per_layer, void* stream) {
+    if (!args_dev || wgs_per_layer <= 0 || (int64_t)n * wgs_per_layer > 65535) return SISR_E_BADARG;
+    if (int e = wtrunk_batch_check(descs, n)) return e;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    constexpr int lds_bytes = 2 * (WT_XBYTES + WT_DBYTES) + 2 * 64 * 4;
+    const WTrunkArgs* table = static_cast<const WTrunkArgs*>(args_dev);
+    const dim3 grid(n * wgs_per_layer);
+    if (descs[0].gpro_mode == SISR_PRO_BNBWD) {
+        static SisrLdsCap cap;
+        if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&wgrad_trunk_table_kernel<SISR_PRO_BNBWD>), lds_bytes)) return e;
+        hipLaunchKernelGGL((wgrad_trunk_table_kernel<SISR_PRO_BNBWD>), grid, dim3(WT_THREADS), lds_bytes, st, table, wgs_per_layer);
+    } else {
+        static SisrLdsCap cap;
+        if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&wgrad_trunk_table_kernel<SISR_PRO_BNACT_BWD>), lds_bytes)) return e;
+        hipLaunchKernelGGL((wgrad_trunk_table_kernel<SISR_PRO_BNACT_BWD>), grid, dim3(WT_THREADS), lds_bytes, st, table, wgs_per_layer);
+    }
+    SISR_CHECK_LAUNCH();
+    return 0;
 }

@@ -879,6 +879,7 @@ class WgradDeepBatch:
 
     def __init__(self):
         self.items = []
+        self.trunk = []                 # layers the persistent trunk kernel keeps (LR 96): batched per gradient-prologue kind
 
     def add(self, prep, x_op, dy_op):
         """-> reduced-gradient buffer, or None when the layer does not qualify (the caller then runs conv_wgrad as usual)"""
@@ -897,7 +898,13 @@ class WgradDeepBatch:
             return None
         if lib.sisr_wgrad_trunk_eligible(C.byref(g)):
             if g.N * g.H * g.W >= int(os.environ.get('SISR_WGRAD_BATCH_TRUNK_PIXELS', 384 * 128)) or os.environ.get('SISR_WGRAD_BATCH_TRUNK', '1') == '0':
-                return None
+                # the persistent kernel keeps the layer -- and, for the plain trunk layers (Cout = 64), its launches are batched
+                # too (run(): sisr_wgrad_trunk_batch, workgroups [z * wpl, (z + 1) * wpl) serve layer z)
+                if g.Cout != 64 or os.environ.get('SISR_WGRAD_TRUNK_BATCH', '1') == '0':
+                    return None
+                red = torch.empty((g.slab_stride,), dtype=torch.float32, device=x_op.x1.device)
+                self.trunk.append((prep, g, x_op, dy_op, red))
+                return red
             # (sisr_wgrad_bf16_slab_lead answers for the trunk kernel then: the same SISR_SLAB_BF16 rule as wgrad_deep.hip's)
         red = torch.empty((g.slab_stride,), dtype=torch.float32, device=x_op.x1.device)
         self.items.append((prep, g, x_op, dy_op, red))              # (the operands' tensors stay alive until run())
@@ -905,6 +912,7 @@ class WgradDeepBatch:
 
     def run(self, pending):
         """launch what was collected; the slab sums are left with `pending` (PendingSlabs: the caller flushes it)"""
+        self._run_trunk(pending)
         if not self.items:
             return
         lib = L.lib()
@@ -942,6 +950,34 @@ class WgradDeepBatch:
             L.check(lib.sisr_wgrad_deep_batch(table, dev.data_ptr(), len(group), _stream()), 'sisr_wgrad_deep_batch')
             KERNEL_COUNTS['wgrad_deep'] = KERNEL_COUNTS.get('wgrad_deep', 0) + len(group)
             KERNEL_COUNTS['wgrad_deep_batch'] = KERNEL_COUNTS.get('wgrad_deep_batch', 0) + 1
+
+
+    def _run_trunk(self, pending):
+        if not self.trunk:
+            return
+        lib = L.lib()
+        items, self.trunk = self.trunk, []
+        groups = {}
+        for it in items:
+            groups.setdefault(it[1].gpro_mode, []).append(it)
+        nbytes = lib.sisr_wgrad_trunk_batch_arg_bytes()
+        for group in groups.values():
+            n = len(group)
+            # 256 workgroup slots over the layers: every workgroup walks its share of ONE layer's tiles back to back (17 layers of 1,152
+            # tiles: 15 workgroups x 77; alone, a layer is 231 workgroups x 5 with a tenth of the chip idle)
+            wpl = max(1, min(256 // n, 231))
+            table = (L.WgradDesc * n)()
+            for i, (prep, g, x_op, dy_op, red) in enumerate(group):
+                slab = torch.empty((wpl, g.slab_stride), dtype=torch.float32, device=red.device)
+                g.slab = slab.data_ptr()
+                g.bias_slab = slab.data_ptr() + 4 * g.slab_elems
+                table[i] = g
+                pending.jobs.append((slab, red, wpl, g.slab_stride, int(lib.sisr_wgrad_bf16_slab_lead(C.byref(g)))))
+            args = (C.c_char * (n * nbytes))()
+            L.check(lib.sisr_wgrad_trunk_batch_args(table, n, C.addressof(args)), 'sisr_wgrad_trunk_batch_args')
+            dev = _table_to_device(args, group[0][4].device)
+            L.check(lib.sisr_wgrad_trunk_batch(table, dev.data_ptr(), n, wpl, _stream()), 'sisr_wgrad_trunk_batch')
+            KERNEL_COUNTS['wgrad_trunk_batch'] = KERNEL_COUNTS.get('wgrad_trunk_batch', 0) + 1
 
 
 class WeightGradBatch:
