@@ -284,6 +284,11 @@ int sisr_wgrad_deep_batch(const SisrWgradDesc *table_host, const SisrWgradDesc *
 int sisr_wgrad_trunk_batch_arg_bytes(void);
 int sisr_wgrad_trunk_batch_args(const SisrWgradDesc *descs, int32_t n, void *args_host);
 int sisr_wgrad_trunk_batch(const SisrWgradDesc *descs, const void *args_dev, int32_t n, int32_t wgs_per_layer, void *stream);
+/* ... and for the fp32-tensor trunk kernel (wgrad_trunk_f32.hip; exact fp32 or, with mfma_split set on every member, the split
+ * contraction): descriptors sisr_wgrad_trunk_f32_eligible accepts, Cout = 64, one gradient-prologue kind, one mfma_split setting */
+int sisr_wgrad_trunk_f32_batch_arg_bytes(void);
+int sisr_wgrad_trunk_f32_batch_args(const SisrWgradDesc *descs, int32_t n, void *args_host);
+int sisr_wgrad_trunk_f32_batch(const SisrWgradDesc *descs, const void *args_dev, int32_t n, int32_t wgs_per_layer, void *stream);
 int sisr_conv2d_wgrad_bf16(const SisrWgradDesc *d, void *stream);
 /* The trunk geometry with bf16 NHWC operands (x prologue NONE / ACT / AFFINE_ACT, gradient prologue BNBWD /
  * BNACT_BWD) runs on the persistent kernel of wgrad_trunk.hip behind sisr_conv2d_wgrad_bf16: one slab per workgroup,

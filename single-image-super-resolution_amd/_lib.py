@@ -139,6 +139,9 @@ _SIGS = {
     'sisr_wgrad_trunk_batch_arg_bytes': [],
     'sisr_wgrad_trunk_batch_args': [C.POINTER(WgradDesc), _i32, _f],
     'sisr_wgrad_trunk_batch': [C.POINTER(WgradDesc), _f, _i32, _i32, _f],
+    'sisr_wgrad_trunk_f32_batch_arg_bytes': [],
+    'sisr_wgrad_trunk_f32_batch_args': [C.POINTER(WgradDesc), _i32, _f],
+    'sisr_wgrad_trunk_f32_batch': [C.POINTER(WgradDesc), _f, _i32, _i32, _f],
     'sisr_conv2d_wgrad_bf16': [C.POINTER(WgradDesc), _f],
     'sisr_tr16_selftest': [_f, _f],
     'sisr_slab_reduce_f32': [_f, _f, _i32, _i64, _i64, _f],

@@ -20,6 +20,7 @@
 #include "sisr_bf16_stage.h"
 
 #include <algorithm>
+#include <cstring>
 #include <cstdlib>
 #include <type_traits>
 
@@ -105,9 +106,10 @@ __device__ __forceinline__ bf16x8 ws_frag(const unsigned char* p) {
 // pixels of a tile row) as hi*hi + hi*lo + lo*hi over (hi, lo) bf16 pairs of both fp32 operands: 108 MFMAs of 32 cycles per
 // tile and wave instead of 288 of 64.  The producers split while they stage; the operands are fetched with transposing reads
 // as in wgrad_trunk.hip.  Tensors in HBM, prologue arithmetic, bias sums, accumulation and the slab are the fp32 kernel's.
+// wg_index / wg_count: this workgroup's place among the workgroups that serve `a` (see wgrad_trunk_f32_table_kernel); lds: [2
+// buffers][x halo image | dy image]
 template <int GPRO, bool SPLIT>
-__global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WTrunkF32Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];        // [2 buffers][x halo image | dy image]
+__device__ __forceinline__ void wgrad_trunk_f32_body(const WTrunkF32Args& a, const int wg_index, const int wg_count, unsigned char* lds) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,8 +124,8 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
         tx = rem - ty * a.tiles_x;
         return (unsigned)(((n * a.H + ty * WF_TH) * a.W + tx * WF_TW) * 256);
     };
-    const int cg = blockIdx.x & ((1 << a.glog) - 1);                    // cout group (shuffle phase) of this workgroup
-    const int t_first = blockIdx.x >> a.glog, t_step = gridDim.x >> a.glog;
+    const int cg = wg_index & ((1 << a.glog) - 1);                      // cout group (shuffle phase) of this workgroup
+    const int t_first = wg_index >> a.glog, t_step = wg_count >> a.glog;
     float* sl = a.slab + (int64_t)t_first * a.slab_stride;
     constexpr int XB = SPLIT ? WS_XBYTES : WF_XBYTES, BUF = SPLIT ? WS_XBYTES + WS_DBYTES : WF_XBYTES + WF_DBYTES, PB = SPLIT ? WS_PB : WF_PB;
     // (accounting marks of thread 0, a consumer: 4 = role state ready, 5 = first barrier passed, 6 = tile loop done, 7 = end)
@@ -354,6 +356,22 @@ __global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WT
     WFA_MARK(7);
 }
 
+template <int GPRO, bool SPLIT>
+__global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_kernel(const WTrunkF32Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    wgrad_trunk_f32_body<GPRO, SPLIT>(a, blockIdx.x, gridDim.x, lds);
+}
+
+// several layers of one gradient-prologue kind in ONE launch (as wgrad_trunk.hip's table kernel): workgroups [z * wpl, (z + 1) * wpl)
+// serve table[z] and write wpl slabs per layer instead of one per CU (256 x 147 KB written and re-read per layer)
+template <int GPRO, bool SPLIT>
+__global__ void __launch_bounds__(WF_THREADS, 2) wgrad_trunk_f32_table_kernel(const WTrunkF32Args* __restrict__ table, const int wpl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int z = (int)blockIdx.x / wpl;
+    const WTrunkF32Args a = table[z];
+    wgrad_trunk_f32_body<GPRO, SPLIT>(a, (int)blockIdx.x - z * wpl, wpl, lds);
+}
+
 // ---- host ----------------------------------------------------------------------------------------------------------
 static int wf_grid(const SisrWgradDesc* d) {
     const int total = d->N * (d->H / WF_TH) * (d->W / WF_TW);
@@ -413,12 +431,22 @@ static int launch_wf(const WTrunkF32Args& a, bool split, int grid, hipStream_t s
     return split ? launch_wf_t<GPRO, true>(a, grid, st) : launch_wf_t<GPRO, false>(a, grid, st);
 }
 
+static WTrunkF32Args wf_args(const SisrWgradDesc* d);
+
 // called by sisr_conv2d_wgrad_f32 for eligible descriptors
 int sisr_wgrad_trunk_f32_launch(const SisrWgradDesc* d, hipStream_t st) {
     if (operand_needs_x2(d->gpro_mode) && !d->g2) return SISR_E_BADARG;
     if (d->pro_mode == SISR_PRO_AFFINE_ACT && (!d->pa || !d->pd)) return SISR_E_BADARG;
     if (d->gpro_mode != SISR_PRO_ACT_BWD && (!d->qa || !d->qb || !d->qd || (d->gpro_mode == SISR_PRO_BNACT_BWD && (!d->qs || !d->qt))))
         return SISR_E_BADARG;
+    const WTrunkF32Args a = wf_args(d);
+    const int grid = wf_grid(d);
+    if (d->gpro_mode == SISR_PRO_ACT_BWD) return launch_wf<SISR_PRO_ACT_BWD>(a, d->mfma_split != 0, grid, st);
+    if (d->gpro_mode == SISR_PRO_BNBWD) return launch_wf<SISR_PRO_BNBWD>(a, d->mfma_split != 0, grid, st);
+    return launch_wf<SISR_PRO_BNACT_BWD>(a, d->mfma_split != 0, grid, st);
+}
+
+static WTrunkF32Args wf_args(const SisrWgradDesc* d) {
     WTrunkF32Args a{};
     a.x1 = d->x1; a.g1 = d->g1; a.g2 = d->g2;
     a.pa = d->pa; a.pd = d->pd; a.xslope_p = d->pro_slope_p; a.xslope = d->pro_slope;
@@ -430,8 +458,53 @@ int sisr_wgrad_trunk_f32_launch(const SisrWgradDesc* d, hipStream_t st) {
     a.m_tiles_x = fdiv_magic(a.tiles_x); a.m_per_img = fdiv_magic(a.per_img);
     a.xpro = d->pro_mode;
     a.glog = d->Cout == 256 ? 2 : 0; a.cout_pad = d->Cout == 256 ? 256 : 64; a.gshuffle = d->g_mode == SISR_X_NHWC_UNSHUFFLE2 ? 1 : 0;
-    const int grid = wf_grid(d);
-    if (d->gpro_mode == SISR_PRO_ACT_BWD) return launch_wf<SISR_PRO_ACT_BWD>(a, d->mfma_split != 0, grid, st);
-    if (d->gpro_mode == SISR_PRO_BNBWD) return launch_wf<SISR_PRO_BNBWD>(a, d->mfma_split != 0, grid, st);
-    return launch_wf<SISR_PRO_BNACT_BWD>(a, d->mfma_split != 0, grid, st);
+    return a;
+}
+
+// ---- a batch of trunk layers (Cout = 64, one gradient-prologue kind, one mfma_split setting) --------------------------------------
+extern "C" int sisr_wgrad_trunk_f32_batch_arg_bytes(void) { return (int)sizeof(WTrunkF32Args); }
+
+static int wf_batch_check(const SisrWgradDesc* descs, int n) {
+    if (!descs || n <= 0 || n > 4096) return SISR_E_BADARG;
+    for (int i = 0; i < n; ++i) {
+        const SisrWgradDesc* d = descs + i;
+        if (!sisr_wgrad_trunk_f32_eligible(d) || d->Cout != 64 || d->gpro_mode != descs[0].gpro_mode) return SISR_E_BADARG;
+        if ((d->mfma_split != 0) != (descs[0].mfma_split != 0)) return SISR_E_BADARG;
+        if (!d->x1 || !d->g1 || !d->g2 || !d->slab || d->slab_stride < d->slab_elems) return SISR_E_BADARG;
+        if (d->pro_mode == SISR_PRO_AFFINE_ACT && (!d->pa || !d->pd)) return SISR_E_BADARG;
+        if (!d->qa || !d->qb || !d->qd || (d->gpro_mode == SISR_PRO_BNACT_BWD && (!d->qs || !d->qt))) return SISR_E_BADARG;
+    }
+    return 0;
+}
+
+extern "C" int sisr_wgrad_trunk_f32_batch_args(const SisrWgradDesc* descs, int32_t n, void* args_host) {
+    if (!args_host) return SISR_E_BADARG;
+    if (int e = wf_batch_check(descs, n)) return e;
+    for (int i = 0; i < n; ++i) {
+        const WTrunkF32Args a = wf_args(descs + i);
+        std::memcpy(static_cast<unsigned char*>(args_host) + (size_t)i * sizeof(WTrunkF32Args), &a, sizeof(WTrunkF32Args));
+    }
+    return 0;
+}
+
+template <int GPRO, bool SPLIT>
+static int launch_wf_table(const WTrunkF32Args* table, int n, int wpl, hipStream_t st) {
+    constexpr int lds_bytes = SPLIT ? 2 * (WS_XBYTES + WS_DBYTES) : 2 * (WF_XBYTES + WF_DBYTES);
+    static SisrLdsCap cap;
+    if (int e = sisr_raise_lds_cap(cap, reinterpret_cast<const void*>(&wgrad_trunk_f32_table_kernel<GPRO, SPLIT>), lds_bytes)) return e;
+    hipLaunchKernelGGL((wgrad_trunk_f32_table_kernel<GPRO, SPLIT>), dim3(n * wpl), dim3(WF_THREADS), lds_bytes, st, table, wpl);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sisr_wgrad_trunk_f32_batch(const SisrWgradDesc* descs, const void* args_dev, int32_t n, int32_t wgs_per_layer, void* stream) {
+    if (!args_dev || wgs_per_layer <= 0 || (int64_t)n * wgs_per_layer > 65535) return SISR_E_BADARG;
+    if (int e = wf_batch_check(descs, n)) return e;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const WTrunkF32Args* table = static_cast<const WTrunkF32Args*>(args_dev);
+    const bool split = descs[0].mfma_split != 0;
+    if (descs[0].gpro_mode == SISR_PRO_BNBWD)
+        return split ? launch_wf_table<SISR_PRO_BNBWD, true>(table, n, wgs_per_layer, st) : launch_wf_table<SISR_PRO_BNBWD, false>(table, n, wgs_per_layer, st);
+    return split ? launch_wf_table<SISR_PRO_BNACT_BWD, true>(table, n, wgs_per_layer, st)
+                 : launch_wf_table<SISR_PRO_BNACT_BWD, false>(table, n, wgs_per_layer, st);
 }

@@ -883,8 +883,20 @@ class WgradDeepBatch:
 
     def add(self, prep, x_op, dy_op):
         """-> reduced-gradient buffer, or None when the layer does not qualify (the caller then runs conv_wgrad as usual)"""
-        if not prep.kinds[2] or os.environ.get('SISR_WGRAD_BATCH', '1') == '0':
+        if os.environ.get('SISR_WGRAD_BATCH', '1') == '0':
             return None
+        if not prep.kinds[2]:
+            # fp32-tensor builds: the persistent trunk kernel's plain layers (Cout = 64) are batched like the bf16 build's
+            g = _copy_struct(prep.plans[2])
+            x_op.fill(g)
+            dy_op.fill(g, g=True)
+            g.mfma_split = mfma_split()
+            if (g.Cout != 64 or os.environ.get('SISR_WGRAD_TRUNK_BATCH', '1') == '0' or dy_op.mode != L.X_NHWC
+                    or not L.lib().sisr_wgrad_trunk_f32_eligible(C.byref(g))):
+                return None
+            red = torch.empty((g.slab_stride,), dtype=torch.float32, device=x_op.x1.device)
+            self.trunk.append((prep, g, x_op, dy_op, red))
+            return red
         g = _copy_struct(prep.plans[2])
         if not g.deep.enabled:
             return None
@@ -959,10 +971,14 @@ class WgradDeepBatch:
         items, self.trunk = self.trunk, []
         groups = {}
         for it in items:
-            groups.setdefault(it[1].gpro_mode, []).append(it)
-        nbytes = lib.sisr_wgrad_trunk_batch_arg_bytes()
-        for group in groups.values():
+            groups.setdefault((bool(it[0].kinds[2]), it[1].gpro_mode), []).append(it)
+        for (is_bf16, _), group in groups.items():
             n = len(group)
+            f_bytes, f_args, f_run, f_lead = ((lib.sisr_wgrad_trunk_batch_arg_bytes, lib.sisr_wgrad_trunk_batch_args, lib.sisr_wgrad_trunk_batch,
+                                               lambda gg: int(lib.sisr_wgrad_bf16_slab_lead(C.byref(gg)))) if is_bf16 else
+                                              (lib.sisr_wgrad_trunk_f32_batch_arg_bytes, lib.sisr_wgrad_trunk_f32_batch_args,
+                                               lib.sisr_wgrad_trunk_f32_batch, lambda gg: 0))
+            nbytes = f_bytes()
             # 256 workgroup slots over the layers: every workgroup walks its share of ONE layer's tiles back to back (17 layers of 1,152
             # tiles: 15 workgroups x 77; alone, a layer is 231 workgroups x 5 with a tenth of the chip idle)
             wpl = max(1, min(256 // n, 231))
@@ -972,11 +988,11 @@ class WgradDeepBatch:
                 g.slab = slab.data_ptr()
                 g.bias_slab = slab.data_ptr() + 4 * g.slab_elems
                 table[i] = g
-                pending.jobs.append((slab, red, wpl, g.slab_stride, int(lib.sisr_wgrad_bf16_slab_lead(C.byref(g)))))
+                pending.jobs.append((slab, red, wpl, g.slab_stride, f_lead(g)))
             args = (C.c_char * (n * nbytes))()
-            L.check(lib.sisr_wgrad_trunk_batch_args(table, n, C.addressof(args)), 'sisr_wgrad_trunk_batch_args')
+            L.check(f_args(table, n, C.addressof(args)), 'sisr_wgrad_trunk(_f32)_batch_args')
             dev = _table_to_device(args, group[0][4].device)
-            L.check(lib.sisr_wgrad_trunk_batch(table, dev.data_ptr(), n, wpl, _stream()), 'sisr_wgrad_trunk_batch')
+            L.check(f_run(table, dev.data_ptr(), n, wpl, _stream()), 'sisr_wgrad_trunk(_f32)_batch')
             KERNEL_COUNTS['wgrad_trunk_batch'] = KERNEL_COUNTS.get('wgrad_trunk_batch', 0) + 1
 
 
