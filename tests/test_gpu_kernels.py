@@ -622,6 +622,54 @@ def test_trunk_kernel_weight_gradient_role(E, L, shape, xpro, gpro, monkeypatch)
         E.set_precision('fp32')
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp32', 'bf16x3'])
+def test_trunk_weight_gradients_of_several_layers_in_one_launch(E, L, precision, monkeypatch):
+    """engine.WgradDeepBatch._run_trunk -> sisr_wgrad_trunk_batch / sisr_wgrad_trunk_f32_batch: five trunk layers (three with the
+    BatchNorm-backward prologue, two with the activation form: two launches, workgroups [z * wpl, (z + 1) * wpl) serve layer z) against
+    the same layers launched alone -- same per-tile arithmetic, only the partition into slabs differs -- at (16, 96, 96), the size the
+    benchmark runs, and at a small size walked by few workgroups"""
+    bc = lambda v: v[None, :, None, None]
+    monkeypatch.setenv('SISR_STORAGE', 'bf16' if precision == 'bf16' else 'f32')
+    monkeypatch.setenv('SISR_WGRAD_BATCH_TRUNK_PIXELS', '0')      # (the bf16 build hands small trunk layers to wgrad_deep's batch: not here)
+    E.set_precision(precision)
+    try:
+        for n, h, w in ((16, 96, 96), (2, 16, 32)):
+            members = []
+            for i, gpro in enumerate(('bnbwd', 'bnact_bwd', 'bnbwd', 'bnbwd', 'bnact_bwd')):
+                s0 = 400 + 20 * i
+                wt = _rand((64, 64, 3, 3), s0, (1.0 / 576) ** 0.5)
+                ref = FakeConv(wt.cuda(), _rand((64,), s0 + 1, 0.1).cuda(), E.ConvGeom(64, 64, 3, 1, 1))
+                p = E.prepare_weights([(ref, n, h, w)], training=True)[0][0]
+                dt = torch.bfloat16 if p.kinds[2] else torch.float32
+                xd = nhwc(_rand((n, 64, h, w), s0 + 2) * 2.0).cuda().to(dt)
+                gd, cd = nhwc(_rand((n, 64, h, w), s0 + 3)).cuda().to(dt), nhwc(_rand((n, 64, h, w), s0 + 4) * 2.0).cuda().to(dt)
+                x_op = E.Operand.affine_act(xd, (_rand((64,), s0 + 5) * 0.5 + 1.0).cuda(), (_rand((64,), s0 + 6) * 0.3).cuda(), torch.tensor([0.2]).cuda())
+                kw = dict(pa=(_rand((64,), s0 + 7) * 0.3 + 1.0).cuda(), pb=(_rand((64,), s0 + 8) * 0.2).cuda(), pd=(_rand((64,), s0 + 9) * 0.1).cuda())
+                if gpro == 'bnact_bwd':
+                    kw.update(ps=(_rand((64,), s0 + 10) * 0.5 + 1.0).cuda(), pt=(_rand((64,), s0 + 11) * 0.3).cuda(), slope=torch.tensor([0.2]).cuda())
+                dy_op = E.Operand(gd, tuple(cd.shape), pro=L.PRO_BNACT_BWD if gpro == 'bnact_bwd' else L.PRO_BNBWD, x2=cd, **kw)
+                members.append((p, ref, x_op, dy_op))
+            alone = [E.conv_wgrad(p, x_op, dy_op) for p, ref, x_op, dy_op in members]
+            wb, pending = E.WgradDeepBatch(), E.PendingSlabs()
+            before = E.KERNEL_COUNTS.get('wgrad_trunk_batch', 0)
+            reds = [wb.add(p, x_op, dy_op) for p, ref, x_op, dy_op in members]
+            assert all(r is not None for r in reds) and len(wb.trunk) == 5 and wb.items == []
+            wb.run(pending)
+            assert E.KERNEL_COUNTS.get('wgrad_trunk_batch', 0) == before + 2 and len(pending.jobs) == 5
+            pending.flush()
+            tol = 5e-3 if precision == 'bf16' else (1e-5 if precision == 'fp32' else 1e-4)       # (bf16: slabs rounded to bf16, 2^-9 each)
+            # compared un-packed: the fp32 slab layout has padding rows that no kernel writes (whatever the allocation held)
+            for reds_ in (reds, alone):
+                wg = E.WeightGradBatch()
+                for (p, ref, _, _), r in zip(members, reds_):
+                    wg.add(p, r)
+                reds_[:] = [wg.run()[id(ref)] for p, ref, _, _ in members]
+            for (gw, gb), (gw1, gb1) in zip(reds, alone):
+                assert maxrel(gw, gw1) < tol and maxrel(gb, gb1) < tol, (precision, n, h, w, maxrel(gw, gw1), maxrel(gb, gb1))
+    finally:
+        E.set_precision('fp32')
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('xpro,gpro', [('none', 'bnbwd'), ('act', 'bnact_bwd'), ('affine_act', 'bnbwd'), ('affine_act', 'bnact_bwd')])
 @pytest.mark.parametrize('shape', [(2, 12, 16)] + TRUNK_SHAPES[1:])
