@@ -201,11 +201,6 @@ __device__ __forceinline__ void deep_epilogue(const SisrConvDesc& d, f32x16 (&ac
     }
     __syncthreads();
 
-#ifdef DP_DBG_DUMP
-    if (mt == 0 && nt == 0 && wave == 0 && d.deep_ws) {
-        d.deep_ws[lane] = acc[0][0][0]; d.deep_ws[64 + lane] = acc[0][0][1]; d.deep_ws[128 + lane] = acc[0][0][4];
-    }
-#endif
     const float scale = d.epi_scale_p ? d.epi_scale_p[0] : 1.f;
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) {
@@ -382,13 +377,6 @@ __device__ __forceinline__ void deep_epilogue(const SisrConvDesc& d, f32x16 (&ac
         const int cp = cout_base + wn * WN + oc * 8;
         const unsigned vo = ro >= 0 ? (unsigned)(ro + cp) * 2u : 0x80000000u;
         const s16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-#ifdef DP_DBG_DUMP
-        if (mt == 0 && nt == 0 && wave == 0 && d.deep_ws && ps == 0) {
-            d.deep_ws[256 + lane] = (float)ro; d.deep_ws[320 + lane] = (float)vo;
-            d.deep_ws[384 + lane] = bf16_bits_to_f32((unsigned short)lo[0]); d.deep_ws[448 + lane] = bf16_bits_to_f32((unsigned short)lo[1]);
-            d.deep_ws[512 + lane] = acc[0][0][0];
-        }
-#endif
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v8), ry, vo, 0, 0);
     }
 }

@@ -573,17 +573,12 @@ def _table_to_device(table, dev):
     return host.to(dev, non_blocking=True)
 
 
-DEEP_DEBUG = None
-
-
 def _attach_deep(desc, image, dev, prep):
     """descriptor planned for conv_deep.hip: hand it that family's weight image (instead of `wpk`), the 1 / sigma its epilogue
     applies (the image holds W_orig) and a split workspace"""
     desc.wdeep, desc.wpk = image.data_ptr(), None
     desc.epi_scale_p = prep.inv_sigma.data_ptr()
     ws = None
-    if DEEP_DEBUG is not None:                      # developer builds of conv_deep.hip (-DDP_DBG_DUMP) leave values here
-        desc.deep_ws = DEEP_DEBUG.data_ptr()
     if desc.deep.ws_bytes > 0:
         ws = torch.empty((desc.deep.ws_bytes // 4,), dtype=torch.float32, device=dev)
         desc.deep_ws = ws.data_ptr()
