@@ -116,3 +116,39 @@ def test_bf16_mode_trains_like_the_fp32_build():
     a, b = traj['fp32'], traj['bf16']
     assert a[-1] < 0.7 * a[0] and b[-1] < 0.7 * b[0], (a[0], a[-1], b[0], b[-1])
     assert max(abs(x - y) / x for x, y in zip(a, b)) < 0.01, [round(abs(x - y) / x, 4) for x, y in zip(a, b)]
+
+
+@pytest.mark.parametrize('net_kind', ['discriminator', 'generator_lr48', 'generator_lr96'])
+def test_batched_and_per_layer_weight_gradients_agree(bf16_engine, net_kind, monkeypatch):
+    """the backward schedules collect the weight gradients of a pass and launch them together (engine.WgradDeepBatch: wgrad_deep.hip's
+    flat-grid batch for D and for the LR 48 trunk, the persistent kernel's table launch for the LR 96 trunk); SISR_WGRAD_BATCH=0 launches
+    every layer on its own.  Same forward, same operands, same per-tile arithmetic: every parameter gradient agrees to the rounding of
+    the bf16 slabs (the partition into slabs is what differs)."""
+    E = bf16_engine
+    mg, md = pkg('model_generator'), pkg('model_discriminator')
+    torch.manual_seed(0)
+    gx = torch.Generator().manual_seed(4)
+    if net_kind == 'discriminator':
+        net = md.Discriminator((3, 96, 96), [64, 64, 128, 128, 256, 256, 512, 512], [1, 2, 1, 2, 1, 2, 1, 2]).cuda().train()
+        x = (torch.rand(16, 3, 96, 96, generator=gx) * 2 - 1).cuda()
+        key = 'wgrad_deep_batch'
+    else:
+        lr = 48 if net_kind.endswith('48') else 96
+        net = mg.Generator(4, 64, 256, [2], use_sn=True).cuda().train()
+        x = (torch.rand(16, 3, lr, lr, generator=gx) * 2 - 1).cuda()
+        key = 'wgrad_deep_batch' if lr == 48 else 'wgrad_trunk_batch'
+    state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    grads = {}
+    for sw in ('1', '0'):
+        monkeypatch.setenv('SISR_WGRAD_BATCH', sw)
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        before = E.KERNEL_COUNTS.get(key, 0)
+        out = net(x)
+        r = torch.rand(out.shape, generator=torch.Generator().manual_seed(5)).cuda() - 0.5
+        (out * r).sum().backward()
+        assert (E.KERNEL_COUNTS.get(key, 0) > before) == (sw == '1'), (key, sw)
+        grads[sw] = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    for k in grads['1']:
+        a, b = grads['1'][k], grads['0'][k]
+        assert float((a - b).abs().max()) <= 6e-3 * max(float(b.abs().max()), 1e-30), k
