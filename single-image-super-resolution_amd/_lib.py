@@ -180,6 +180,7 @@ _SIGS = {
     'sisr_fc_head_forward': [_f, _f, _f, _f, _f, _f32, _f, _f, _f, _i32, _i32, _i32, _f],
     'sisr_fc_head_backward': [_f, _f, _f, _f, _f32, _f, _f, _f, _f, _i32, _i32, _f],
     'sisr_fc1_dgrad': [_f, _f, _f, _i32, _i32, _i32, _f],
+    'sisr_fc_wgrad_rows': [_f, _f, _f32, _f, _i32, _i32, _i32, _f],
     'sisr_resize_coeffs': [_i32, _i32, _f, _f],
     'sisr_resize_u8_normalize': [_f, _f, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f, _i32, _f, _f, _i32, _f32, _f32, _f],
     'sisr_bicubic_fwd': [_f, _f, _i32, _i32, _i32, _i32, _i32, _i32, _f],

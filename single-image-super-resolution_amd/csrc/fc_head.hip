@@ -205,3 +205,50 @@ extern "C" int sisr_fc1_dgrad(const float* d1, const float* W1, float* dx, int32
     SISR_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- dW1 from MANY rows: the data-parallel exchange of the classifier head's weight gradient --------------------------------------
+// dW[n][k] = scale * sum_b dy[b][n] * x[b][k] is a rank-B product of two small factors (B = 16 rows per rank).  Exchanging the 75-302 MB
+// product with an all-reduce costs 2 (N - 1) / N of it per GPU and pass; exchanging the FACTORS costs N x 1.2-4.8 MB, after which every
+// rank forms the mean gradient itself from all N x 16 rows (distributed.GradReducer.gather, discriminator_engine.run_backward).
+// Exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32: A = dy^T tile 32 n x 2 b, B = x tile 2 b x 32 k): a wave owns 32 columns k,
+// keeps its x fragments of ALL rows in registers (B / 2 of them) and walks the n tiles; workgroup = 4 waves = 128 columns.
+// B <= 256, even; K % 128 == 0; N % 32 == 0.
+#define FR_MAXSTEPS 128
+template <int STEPS>                 // K steps of two rows provided for (rows >= B read as zeros)
+__global__ void __launch_bounds__(256) fc_wgrad_rows_kernel(const float* __restrict__ dy, const float* __restrict__ x, float scale,
+                                                            float* __restrict__ dW, int B, int K, int N) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int k0 = ((int)blockIdx.x * 4 + wave) * 32;
+    float xf[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) xf[s] = 2 * s + kk < B ? x[(int64_t)(2 * s + kk) * K + k0 + l31] : 0.f;
+    for (int nt = 0; nt < (N >> 5); ++nt) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* dp = dy + (int64_t)kk * N + nt * 32 + l31;
+        // the dy fragments of 16 steps are requested together (L2-resident: the factor is B x N floats), then multiplied
+#pragma unroll
+        for (int s0 = 0; s0 < STEPS; s0 += 16) {
+            float a[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[u] = 2 * (s0 + u) + kk < B ? dp[(int64_t)(2 * (s0 + u)) * N] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = mfma32(a[u], xf[s0 + u], acc);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dW[(int64_t)(nt * 32 + mfma_row(i, lane)) * K + k0 + l31] = acc[i] * scale;
+    }
+}
+
+extern "C" int sisr_fc_wgrad_rows(const float* dy, const float* x, float scale, float* dW, int32_t B, int32_t K, int32_t N, void* stream) {
+    if (!dy || !x || !dW || B <= 0 || B > 2 * FR_MAXSTEPS || K <= 0 || (K & 127) || N <= 0 || (N & 31)) return SISR_E_BADARG;
+    const dim3 grid(K / 128);
+    if (B <= 32) hipLaunchKernelGGL(fc_wgrad_rows_kernel<16>, grid, dim3(256), 0, S_(stream), dy, x, scale, dW, B, K, N);
+    else if (B <= 64) hipLaunchKernelGGL(fc_wgrad_rows_kernel<32>, grid, dim3(256), 0, S_(stream), dy, x, scale, dW, B, K, N);
+    else if (B <= 128) hipLaunchKernelGGL(fc_wgrad_rows_kernel<64>, grid, dim3(256), 0, S_(stream), dy, x, scale, dW, B, K, N);
+    else hipLaunchKernelGGL(fc_wgrad_rows_kernel<128>, grid, dim3(256), 0, S_(stream), dy, x, scale, dW, B, K, N);
+    SISR_CHECK_LAUNCH();
+    return 0;
+}

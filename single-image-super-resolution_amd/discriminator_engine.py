@@ -120,16 +120,30 @@ def run_backward(sv, grad_out, need_dx, sink=None, params=()):
             announced.update(new)
             sink.ready([(by_id[k], grads[k]) for k in new], tag)
 
+    factored = None
     if sv.head:
         d1, dw2, db2, db1 = E.fc_head_backward(grad_out, sv.out, sv.h1, topo.fc2.weight, LEAKY)
-        dw1 = E.fc_wgrad_only(d1, sv.flat, topo.fc1.weight)
+        world = getattr(sink, 'world', 1) if sink is not None else 1
+        if (world > 1 and getattr(sink, 'enabled', False) and hasattr(sink, 'gather') and id(topo.fc1.weight) in by_id
+                and E.fc_wgrad_rows_ok(world * n, sv.flat.shape[1], topo.fc1.weight.shape[0]) and os.environ.get('SISR_FC_FACTORED', '1') != '0'):
+            # data-parallel: the 75-302 MB weight gradient is d1^T x, a rank-16 product -- the ranks exchange the two FACTORS (an
+            # all-gather of N x 1.2-4.8 MB, issued now: it has the whole conv stack's backward to hide behind) and every rank forms
+            # the MEAN gradient itself from all ranks' rows at the end of this schedule (same rows, same kernel: the same bits on
+            # every rank).  Over point-to-point xGMI an all-reduce of the product would cost 2 (N - 1) / N of it per GPU and pass.
+            d1_all = torch.empty((world * n, d1.shape[1]), dtype=d1.dtype, device=d1.device)
+            x_all = torch.empty((world * n, sv.flat.shape[1]), dtype=sv.flat.dtype, device=d1.device)
+            if sink.gather([(d1, d1_all), (sv.flat, x_all)], 'fc1_factors', done=[topo.fc1.weight]):
+                factored = (d1_all, x_all, world)
+        dw1 = E.fc_wgrad_only(d1, sv.flat, topo.fc1.weight) if factored is None else None
     else:
         d2 = E.act_bwd(grad_out, sv.out, 1)                               # sigmoid'
         dx2, dw2, db2 = E.fc_backward(d2, sv.h1, topo.fc2.weight, in_slope=LEAKY)
         d1 = E.act_bwd(dx2, sv.h1, 0, LEAKY)                              # LeakyReLU'
         dflat, dw1, db1 = E.fc_backward(d1, sv.flat, topo.fc1.weight)
     grads[id(topo.fc2.weight)], grads[id(topo.fc2.bias)] = dw2, db2
-    grads[id(topo.fc1.weight)], grads[id(topo.fc1.bias)] = dw1, db1
+    grads[id(topo.fc1.bias)] = db1
+    if dw1 is not None:
+        grads[id(topo.fc1.weight)] = dw1
     if sink is not None:
         flush('fc')                                                       # ... before the data gradient of the head is even launched
     if sv.head:
@@ -175,6 +189,11 @@ def run_backward(sv, grad_out, need_dx, sink=None, params=()):
         raise NotImplementedError('input gradient through a stride-2 first convolution')
     gx = conv_bwd(topo.conv0, x_op, dy0, need_dgrad=need_dx, y_mode=L.Y_NCHW)
     flush('final')
+    if factored is not None:
+        # (replay: this runs in the segment behind the 'final' bucket, which joined the side stream; eager: wait here)
+        sink.wait()
+        announced.add(id(topo.fc1.weight))
+        grads[id(topo.fc1.weight)] = E.fc_wgrad_rows(factored[0], factored[1], topo.fc1.weight, 1.0 / factored[2])
     if sink is not None:
         sink.backward_end()
     return grads, gx

@@ -30,6 +30,10 @@ backward to hide behind -- then the conv layers deepest first.  D runs one backw
 batch, train.py:132,156); every pass announces its own gradients and autograd adds the reduced passes (mean of a sum = sum of
 means).  ``enabled = False`` mutes a reducer for a pass whose gradients are discarded (the G step's pass through D, train.py:174).
 
+The classifier head's weight gradient is NOT reduced at all: it is a rank-16 product ``d1^T x`` of two tensors of 1.2-4.8 MB, so the ranks
+all-gather the FACTORS (``gather()``: N x 1.2-4.8 MB instead of 2 (N - 1) / N x 75-302 MB per GPU and pass over per-link-bound xGMI) and
+every rank forms the mean gradient itself from all N x 16 rows (``sisr_fc_wgrad_rows``, exact fp32, the same bits on every rank).
+
 ``all_reduce_mean()`` is the plain post-backward form (everything that has a ``.grad`` and was not
 already reduced during the backward pass): the path for modules used without ``attach``.
 """
@@ -108,12 +112,54 @@ class GradReducer:
             utag = '%s%s#%d' % (self.name, tag, self._seq)      # unique per announcement (several passes use the same schedule tags)
             if G.segment_boundary(utag):                # the capture is cut here; launch_bucket(utag) runs at replay
                 self._seq += 1
-                self._captured[utag] = ([g for _, g in pairs], [id(p) for p, _ in pairs], tag == FINAL)
+                self._captured[utag] = ([g for _, g in pairs], [id(p) for p, _ in pairs], tag == FINAL, 'reduce')
                 return
             # (not inside a capture: a warm-up run of the function that is about to be captured -- ordinary eager exchange)
         self._launch([g for _, g in pairs])
         self._done.update(id(p) for p, _ in pairs)
         self.stats['early_buckets'] += 1
+
+    def gather(self, pairs, tag, done=()):
+        """pairs: [(local tensor [rows, ...], destination [world * rows, ...])]: all-gather every local tensor into its destination
+        (rank-major) on the side stream -- the exchange of FACTORS of a gradient instead of the gradient (the discriminator's first
+        Linear: its 75-302 MB weight gradient is a rank-16 product of two tensors of 1.2-4.8 MB; every rank then forms the mean itself
+        from all ranks' rows).  Same protocol as ready(): issued at once in eager mode, between two replayed segments under graph
+        replay.  done: the parameters whose gradient this exchange stands for (the post-backward pass must not reduce them again).
+        The consumer calls wait() before it reads the destinations (eager) / reads them in the segment behind the schedule's LAST
+        bucket, which joins the side stream (replay)."""
+        if self.world <= 1 or not pairs or not self.enabled:
+            return False
+        if self._capturing:
+            utag = '%s%s#%d' % (self.name, tag, self._seq)
+            if G.segment_boundary(utag):
+                self._seq += 1
+                self._captured[utag] = (list(pairs), [id(p) for p in done], False, 'gather')
+                return True
+        self._launch_gather(list(pairs))
+        self._done.update(id(p) for p in done)
+        self.stats['early_buckets'] += 1
+        return True
+
+    def wait(self):
+        """eager mode: the compute stream waits for everything issued on the side stream so far (no-op inside a capture: there the
+        schedule's last bucket joins)"""
+        if not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
+            self._join()
+
+    def _launch_gather(self, pairs, static=False):
+        cur, side = self._streams(pairs[0][0].device)
+        if side is None:
+            for src, dst in pairs:
+                dist.all_gather(list(dst.chunk(self.world, dim=0)), src.contiguous(), group=self.group)
+            return
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for src, dst in pairs:
+                dist.all_gather(list(dst.chunk(self.world, dim=0)), src.contiguous(), group=self.group)
+                if not static:                               # (static = tensors of a graph's private pool: never freed)
+                    src.record_stream(side)
+                    dst.record_stream(side)
+        self._dirty = True
 
     def backward_end(self):
         """end of the schedule: from here on autograd may read (clone / accumulate) the announced gradients"""
@@ -127,9 +173,12 @@ class GradReducer:
     # ---- graph replay -----------------------------------------------------------------------------------------
     def launch_bucket(self, tag):
         """between two replayed graph segments: reduce the (static) gradients the finished segment produced"""
-        grads, ids, last = self._captured.get(tag, (None, (), False))
+        grads, ids, last, kind = self._captured.get(tag, (None, (), False, 'reduce'))
         if grads and self.world > 1:
-            self._launch(grads, static=True)
+            if kind == 'gather':
+                self._launch_gather(grads, static=True)
+            else:
+                self._launch(grads, static=True)
             self._launched.add(tag)
             self._done.update(ids)
             self.stats['early_buckets'] += 1
@@ -138,9 +187,12 @@ class GradReducer:
 
     def launch_remaining(self):
         """after the last replayed segment: buckets whose boundary closed the capture (no segment followed them)"""
-        for tag, (grads, ids, _) in self._captured.items():
+        for tag, (grads, ids, _, kind) in self._captured.items():
             if tag not in self._launched and self.world > 1:
-                self._launch(grads, static=True)
+                if kind == 'gather':
+                    self._launch_gather(grads, static=True)
+                else:
+                    self._launch(grads, static=True)
                 self._done.update(ids)
         self._launched = set()
 

@@ -1280,6 +1280,21 @@ def fc1_dgrad(d1, w1):
     return dx
 
 
+def fc_wgrad_rows_ok(rows, k, n):
+    """sisr_fc_wgrad_rows takes the gathered factors of `rows` batch rows (all ranks)"""
+    return rows <= 256 and k % 128 == 0 and n % 32 == 0
+
+
+def fc_wgrad_rows(dy_all, x_all, w, scale):
+    """dW = scale * dy_all^T x_all over the rows of ALL ranks (the gathered factors of the classifier head's weight gradient)"""
+    rows, k = x_all.shape
+    dw = torch.empty_like(w)
+    L.check(L.lib().sisr_fc_wgrad_rows(dy_all.data_ptr(), x_all.data_ptr(), float(scale), dw.data_ptr(), rows, k, w.shape[0], _stream()),
+            'sisr_fc_wgrad_rows')
+    KERNEL_COUNTS['fc_wgrad_rows'] = KERNEL_COUNTS.get('fc_wgrad_rows', 0) + 1
+    return dw
+
+
 def fc_wgrad_only(dy, x, w, in_slope=1.0):
     """dW = dy^T lrelu(x) (no bias gradient, no data gradient)"""
     bsz, k = x.shape

@@ -82,9 +82,47 @@ def main():
     step(); red2.launch_remaining(); red2.finish(); opt2.step()
     res['graph_params_identical'] = same_on_all_ranks()
     res['graph_stats'] = dict(red2.stats)
+    # ---- the discriminator alone: two backward passes per sweep; its head's weight gradient travels as FACTORS (all-gather of d1 and the
+    # flattened features of every rank, the mean formed locally by sisr_fc_wgrad_rows) and must equal the mean of the ranks' local sums ----
+    md = sub('model_discriminator')
+    E = sub('engine')
+    torch.manual_seed(2)
+    net_d0 = md.Discriminator((3, 32, 32), [64, 64, 128, 128, 256], [1, 2, 1, 2, 1]).to(dev).train()
+    sd0 = {k: v.clone() for k, v in net_d0.state_dict().items()}
+    crit0 = torch.nn.BCELoss()
+    lab1, lab0 = torch.full((hr.shape[0],), .9, device=dev), torch.zeros(hr.shape[0], device=dev)
+
+    def d_fwd_bwd():
+        net_d0.zero_grad(set_to_none=True)
+        (crit0(net_d0(hr).view(-1), lab1) + crit0(net_d0(hr.flip(-1)).view(-1), lab0)).backward()
+    d_fwd_bwd()
+    want_d = {}
+    for k, p in net_d0.named_parameters():
+        parts = [torch.empty_like(p.grad) for _ in range(world)]
+        dist.all_gather(parts, p.grad.detach().clone())
+        want_d[k] = sum(parts) / world
+    for mode in ('eager', 'graph'):
+        net_d0.load_state_dict(sd0)
+        rd0 = D.GradReducer(net_d0, world, name='D0:')
+        before = E.KERNEL_COUNTS.get('fc_wgrad_rows', 0)
+        if mode == 'graph':
+            rd0.capture_mode(True)
+            stepd = G.GraphedStep(d_fwd_bwd, between=rd0.launch_bucket)
+            rd0.capture_mode(False)
+            net_d0.load_state_dict(sd0)
+            before = E.KERNEL_COUNTS.get('fc_wgrad_rows', 0) - 2            # (the captured run itself made the two calls)
+            stepd(); rd0.launch_remaining()
+        else:
+            d_fwd_bwd()
+        rd0.finish()
+        torch.cuda.synchronize()
+        res['d_%s_grad_err' % mode] = max(float((p.grad - want_d[k]).abs().max()) / max(float(want_d[k].abs().max()), 1e-20)
+                                          for k, p in net_d0.named_parameters())
+        res['d_%s_factored_products' % mode] = E.KERNEL_COUNTS.get('fc_wgrad_rows', 0) - before
+        res['d_%s_stats' % mode] = dict(rd0.stats)
     # ---- the joint SRGAN iteration (train.py:45-108): ONE G forward, D step (two backward passes through D, every pass announcing
     # its buckets: head first), the discriminator's Adam step between two replayed segments, G step with the D reducer muted ----
-    md, mce = sub('model_discriminator'), sub('model_content_extractor')
+    mce = sub('model_content_extractor')
     torch.manual_seed(1)
     net_g = mg.Generator(4, 64, 256, [2], use_sn=True).to(dev).train()
     net_d = md.Discriminator((3, 32, 32), [64, 64, 128, 128, 256], [1, 2, 1, 2, 1]).to(dev).train()     # 5 convs: fc | convs3 | final

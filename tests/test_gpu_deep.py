@@ -380,3 +380,16 @@ def test_weight_gradients_of_several_layers_in_one_launch(E, L, stride):
         assert maxrel(gw, gw_ref) < TOL and maxrel(gw, gw1) < TOL
         l1 = g.abs().sum(dim=(0, 2, 3))
         assert float(((gb.double().cpu() - g.sum(dim=(0, 2, 3))).abs() / l1.clamp_min(1e-30)).max()) < 2e-3
+
+
+@pytest.mark.parametrize('shape', [(32, 18432, 1024), (48, 2048, 256), (128, 16384, 1024), (2, 128, 32), (200, 1024, 64)])
+def test_classifier_head_weight_gradient_from_gathered_factors(E, shape):
+    """sisr_fc_wgrad_rows: dW = scale * dy^T x over the rows of ALL ranks (exact-fp32 matrix instruction) against torch in double"""
+    rows, k, n = shape
+    dy, x = _rand((rows, n), 91), _rand((rows, k), 92)
+    w = torch.empty(n, k, device='cuda')
+    assert E.fc_wgrad_rows_ok(rows, k, n)
+    got = E.fc_wgrad_rows(dy.cuda(), x.cuda(), w, 1.0 / 8)
+    want = (dy.double().t() @ x.double()) / 8
+    assert maxrel(got, want) < 1e-5
+    assert torch.equal(got, E.fc_wgrad_rows(dy.cuda(), x.cuda(), w, 1.0 / 8))

@@ -38,6 +38,12 @@ def test_two_ranks_end_a_step_with_identical_parameters():
     assert res['eager_params_identical'] and res['graph_params_identical'], res
     assert res['eager_stats'] == {'early_buckets': 3, 'late_buckets': 0}, res     # tail | blocks4 | final, all from inside backward
     assert res['graph_segments'] == 4, res                     # tail | blocks4 | final | autograd hand-over
+    # the discriminator alone: every parameter gradient is the mean of the ranks' local sums over the two passes, and the head's weight
+    # gradient got there as two locally formed products of the gathered factors (one per pass), eager and replayed
+    for mode in ('eager', 'graph'):
+        assert res['d_%s_grad_err' % mode] < 1e-5, res
+        assert res['d_%s_factored_products' % mode] == 2, res
+        assert res['d_%s_stats' % mode]['late_buckets'] == 0, res
     # the joint D + G iteration: both networks end identical on both ranks, eager and replayed; the discriminator's two backward
     # passes of the D step each announced head / convs / final from inside the schedule, its G-step pass announced nothing
     for mode in ('eager', 'graph'):
