@@ -529,7 +529,7 @@ int sisr_fc_head_forward(const float *x, const float *W1, const float *b1, const
 int sisr_fc_head_backward(const float *g, const float *y, const float *h1, const float *W2, float slope, float *d1,
                           float *dW2, float *db2, float *db1, int32_t B, int32_t N, void *stream);
 int sisr_fc1_dgrad(const float *d1, const float *W1, float *dx, int32_t B, int32_t K, int32_t N, void *stream);
-/* dW[n][k] = scale * sum_b dy[b][n] * x[b][k] for MANY rows (B <= 256; K % 128 == 0, N % 32 == 0) on the exact-fp32 matrix instruction:
+/* dW[n][k] = scale * sum_b dy[b][n] * x[b][k] for MANY rows (B <= 256; K % 128 == 0, N % 64 == 0) on the exact-fp32 matrix instruction:
  * the data-parallel form of the classifier head's weight gradient -- ranks exchange the two rank-16 FACTORS (dy, x: N_ranks x 1.2-4.8 MB
  * through an all-gather) instead of all-reducing their 75-302 MB product, and every rank forms the mean itself (scale = 1 / ranks)
  * from all N_ranks x 16 rows: the same bits on every rank. */

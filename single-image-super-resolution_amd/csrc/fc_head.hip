@@ -210,45 +210,64 @@ extern "C" int sisr_fc1_dgrad(const float* d1, const float* W1, float* dx, int32
 // dW[n][k] = scale * sum_b dy[b][n] * x[b][k] is a rank-B product of two small factors (B = 16 rows per rank).  Exchanging the 75-302 MB
 // product with an all-reduce costs 2 (N - 1) / N of it per GPU and pass; exchanging the FACTORS costs N x 1.2-4.8 MB, after which every
 // rank forms the mean gradient itself from all N x 16 rows (distributed.GradReducer.gather, discriminator_engine.run_backward).
-// Exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32: A = dy^T tile 32 n x 2 b, B = x tile 2 b x 32 k): a wave owns 32 columns k,
-// keeps its x fragments of ALL rows in registers (B / 2 of them) and walks the n tiles; workgroup = 4 waves = 128 columns.
-// B <= 256, even; K % 128 == 0; N % 32 == 0.
-#define FR_MAXSTEPS 128
-template <int STEPS>                 // K steps of two rows provided for (rows >= B read as zeros)
-__global__ void __launch_bounds__(256) fc_wgrad_rows_kernel(const float* __restrict__ dy, const float* __restrict__ x, float scale,
-                                                            float* __restrict__ dW, int B, int K, int N) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l31 = lane & 31, kk = lane >> 5;
-    const int k0 = ((int)blockIdx.x * 4 + wave) * 32;
-    float xf[STEPS];
+// Exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32: A = dy^T tile 32 n x 2 b, B = x tile 2 b x 32 k).
+// B <= 256; K % 128 == 0; N % 64 == 0.
+#define FR_MAXROWS 256
+#define FR_CHUNK 64                   // rows staged per round
+#define FR_DP 96                      // LDS row pitch (floats) of the dy^T tile: 64 columns + 32 (the two K rows of a step 32 banks apart)
+#define FR_XP 160                     // ... of the x tile: 128 columns + 32
+// Workgroup = 64 rows n x 128 columns k of dW; wave (wn, wk) = 32 n x 64 k (two accumulators).  The factors' rows are staged 64 at a time
+// into LDS (dy^T tile [64][64], x tile [64][128]: 64 KB, two workgroups per CU -- one loads while the other multiplies): a value of
+// either factor is fetched from memory once per workgroup instead of once per wave and tile.
+__global__ void __launch_bounds__(256, 2) fc_wgrad_rows_kernel(const float* __restrict__ dy, const float* __restrict__ x, float scale,
+                                                               float* __restrict__ dW, int B, int K, int N) {
+    __shared__ __attribute__((aligned(16))) float dys[FR_CHUNK * FR_DP];
+    __shared__ __attribute__((aligned(16))) float xs[FR_CHUNK * FR_XP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kk = lane >> 5, wn = wave >> 1, wk = wave & 1;
+    const int n0 = (int)blockIdx.x * 64, k0 = (int)blockIdx.y * 128;      // (the workgroups that share an x tile are neighbours)
+    f32x16 acc[2];
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s) xf[s] = 2 * s + kk < B ? x[(int64_t)(2 * s + kk) * K + k0 + l31] : 0.f;
-    for (int nt = 0; nt < (N >> 5); ++nt) {
-        f32x16 acc;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const float* dp = dy + (int64_t)kk * N + nt * 32 + l31;
-        // the dy fragments of 16 steps are requested together (L2-resident: the factor is B x N floats), then multiplied
-#pragma unroll
-        for (int s0 = 0; s0 < STEPS; s0 += 16) {
-            float a[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) a[u] = 2 * (s0 + u) + kk < B ? dp[(int64_t)(2 * (s0 + u)) * N] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc = mfma32(a[u], xf[s0 + u], acc);
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    for (int b0 = 0; b0 < B; b0 += FR_CHUNK) {
+        const int nb = min(FR_CHUNK, B - b0);
+        if (b0 > 0) __syncthreads();                          // the previous chunk has been consumed
+        // dy rows: 16 float4 per row; x rows: 32 float4 per row
+        for (int i = tid; i < FR_CHUNK * 16; i += 256) {
+            const int r = i >> 4, c4 = i & 15;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < nb) v = *reinterpret_cast<const f32x4*>(dy + (int64_t)(b0 + r) * N + n0 + c4 * 4);
+            *reinterpret_cast<f32x4*>(dys + r * FR_DP + c4 * 4) = v;
         }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dW[(int64_t)(nt * 32 + mfma_row(i, lane)) * K + k0 + l31] = acc[i] * scale;
+        for (int i = tid; i < FR_CHUNK * 32; i += 256) {
+            const int r = i >> 5, c4 = i & 31;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < nb) v = *reinterpret_cast<const f32x4*>(x + (int64_t)(b0 + r) * K + k0 + c4 * 4);
+            *reinterpret_cast<f32x4*>(xs + r * FR_XP + c4 * 4) = v;
+        }
+        __syncthreads();
+        const float* ap = dys + kk * FR_DP + wn * 32 + l31;
+        const float* bp = xs + kk * FR_XP + wk * 64 + l31;
+        const int ns = (nb + 1) >> 1;                          // (an odd last row pairs with a zero row in LDS)
+#pragma unroll 8
+        for (int s = 0; s < ns; ++s) {
+            const float a = ap[2 * s * FR_DP];
+            acc[0] = mfma32(a, bp[2 * s * FR_XP], acc[0]);
+            acc[1] = mfma32(a, bp[2 * s * FR_XP + 32], acc[1]);
+        }
     }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            dW[(int64_t)(n0 + wn * 32 + mfma_row(i, lane)) * K + k0 + wk * 64 + j * 32 + l31] = acc[j][i] * scale;
 }
 
 extern "C" int sisr_fc_wgrad_rows(const float* dy, const float* x, float scale, float* dW, int32_t B, int32_t K, int32_t N, void* stream) {
-    if (!dy || !x || !dW || B <= 0 || B > 2 * FR_MAXSTEPS || K <= 0 || (K & 127) || N <= 0 || (N & 31)) return SISR_E_BADARG;
-    const dim3 grid(K / 128);
-    if (B <= 32) hipLaunchKernelGGL(fc_wgrad_rows_kernel<16>, grid, dim3(256), 0, S_(stream), dy, x, scale, dW, B, K, N);
-    else if (B <= 64) hipLaunchKernelGGL(fc_wgrad_rows_kernel<32>, grid, dim3(256), 0, S_(stream), dy, x, scale, dW, B, K, N);
-    else if (B <= 128) hipLaunchKernelGGL(fc_wgrad_rows_kernel<64>, grid, dim3(256), 0, S_(stream), dy, x, scale, dW, B, K, N);
-    else hipLaunchKernelGGL(fc_wgrad_rows_kernel<128>, grid, dim3(256), 0, S_(stream), dy, x, scale, dW, B, K, N);
+    if (!dy || !x || !dW || B <= 0 || B > FR_MAXROWS || K <= 0 || (K & 127) || N <= 0 || (N & 63)) return SISR_E_BADARG;
+    hipLaunchKernelGGL(fc_wgrad_rows_kernel, dim3(N / 64, K / 128), dim3(256), 0, S_(stream), dy, x, scale, dW, B, K, N);
     SISR_CHECK_LAUNCH();
     return 0;
 }

@@ -1282,7 +1282,7 @@ def fc1_dgrad(d1, w1):
 
 def fc_wgrad_rows_ok(rows, k, n):
     """sisr_fc_wgrad_rows takes the gathered factors of `rows` batch rows (all ranks)"""
-    return rows <= 256 and k % 128 == 0 and n % 32 == 0
+    return rows <= 256 and k % 128 == 0 and n % 64 == 0
 
 
 def fc_wgrad_rows(dy_all, x_all, w, scale):

@@ -382,7 +382,7 @@ def test_weight_gradients_of_several_layers_in_one_launch(E, L, stride):
         assert float(((gb.double().cpu() - g.sum(dim=(0, 2, 3))).abs() / l1.clamp_min(1e-30)).max()) < 2e-3
 
 
-@pytest.mark.parametrize('shape', [(32, 18432, 1024), (48, 2048, 256), (128, 16384, 1024), (2, 128, 32), (200, 1024, 64)])
+@pytest.mark.parametrize('shape', [(32, 18432, 1024), (48, 2048, 256), (128, 16384, 1024), (2, 128, 64), (200, 1024, 64), (70, 256, 128)])
 def test_classifier_head_weight_gradient_from_gathered_factors(E, shape):
     """sisr_fc_wgrad_rows: dW = scale * dy^T x over the rows of ALL ranks (exact-fp32 matrix instruction) against torch in double"""
     rows, k, n = shape
