@@ -10,6 +10,21 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'gpu_slow: GPU tests left out of the default -m gpu run (the suite stays under 600 s there): the '
+                                       'full-size LR 96 generator comparisons of the frozen split build, whose fp32 twins stay in; '
+                                       'run with -m "gpu or gpu_slow" or SISR_SLOW_TESTS=1')
+
+
+def pytest_collection_modifyitems(config, items):
+    """tests marked gpu_slow run only when asked for by name: -m with gpu_slow in it, or SISR_SLOW_TESTS=1"""
+    if 'gpu_slow' in (config.getoption('-m') or '') or os.environ.get('SISR_SLOW_TESTS') == '1':
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker('gpu_slow') else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 @pytest.fixture(scope='session')

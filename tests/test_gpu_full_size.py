@@ -188,8 +188,18 @@ def _generator_case(lr, init, slopes=None):
     return net, {'kind': 'generator', 'list_scales': [2], 'n_suffix': 0}, state, x, r
 
 
-@pytest.mark.parametrize('f32_build', F32_TENSOR_BUILDS, indirect=True)
-@pytest.mark.parametrize('lr,init', [(48, 'default'), (96, 'synthetic')])
+def _builds_with_slow_split_at_lr96():
+    """(lr, init, build) cases of the full-size generator tests: the frozen split build's LR 96 cases (71 s + 27 s of CPU oracle each) are
+    marked gpu_slow -- the default run keeps the fp32 parity build at both sizes and the split build at LR 48"""
+    out = []
+    for lr, init in ((48, 'default'), (96, 'synthetic')):
+        for b in F32_TENSOR_BUILDS:
+            marks = [pytest.mark.gpu_slow] if (lr == 96 and b != 'fp32') else []
+            out.append(pytest.param(lr, init, b, marks=marks, id='%d-%s-%s' % (lr, init, b)))
+    return out
+
+
+@pytest.mark.parametrize('lr,init,f32_build', _builds_with_slow_split_at_lr96(), indirect=['f32_build'])
 def test_full_size_generator_values_at_1e3_with_nearly_linear_activations(lr, init, f32_build):
     """model_generator.py:86-101 at config.py:79-80's sizes -- Generator(16, 64, 256, [2], use_sn=True), B16, LR 48
     (cfg2's generator: 288 tiles) and LR 96 (the headline workload: 1,152 tiles = 5 / 9 per workgroup, the schedule
@@ -257,8 +267,7 @@ def _flip_aware_compare(net, cfg, state, x, r, strict_keys=(), build='fp32'):
     return out
 
 
-@pytest.mark.parametrize('f32_build', F32_TENSOR_BUILDS, indirect=True)
-@pytest.mark.parametrize('lr,init', [(48, 'default'), (96, 'synthetic')])
+@pytest.mark.parametrize('lr,init,f32_build', _builds_with_slow_split_at_lr96(), indirect=['f32_build'])
 def test_full_size_generator_with_the_references_activations(lr, init, f32_build):
     """the same sizes with the reference's own activations (PReLU 0.25 from the default init / 0.1-0.4 synthetic):
     see _flip_aware_compare.  The last conv and the upscale conv sit behind one PReLU only; everything is held to the
