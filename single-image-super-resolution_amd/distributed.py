@@ -25,8 +25,8 @@ at each flush point (graph.segment_boundary) and ``launch_bucket(tag)`` issues t
 between two replayed segments -- same overlap, the exchange stays ordinary stream work.
 
 The discriminator's schedule (discriminator_engine.run_backward) announces too: the classifier head first -- its 75-302 MB weight
-gradient is 94 % of D's bytes and the FIRST tensor the backward pass produces, so its all-reduce has the whole conv stack's
-backward to hide behind -- then the conv layers deepest first.  D runs one backward pass per forward of the loss (real batch, fake
+gradient is 94 % of D's bytes and the FIRST thing the backward pass produces, so its exchange (of the gradient's factors, see below)
+has the whole conv stack's backward to hide behind -- then the conv layers deepest first.  D runs one backward pass per forward of the loss (real batch, fake
 batch, train.py:132,156); every pass announces its own gradients and autograd adds the reduced passes (mean of a sum = sum of
 means).  ``enabled = False`` mutes a reducer for a pass whose gradients are discarded (the G step's pass through D, train.py:174).
 
